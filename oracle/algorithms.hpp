@@ -1,0 +1,523 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see voxel_map.hpp header).  PARITY UNPINNED.
+//
+// CPU restatement of the reference's L4 filters and of the third-party PCL pieces the
+// hot path calls.  [3P] marks behaviour restated from PCL 1.10 /
+// FLANN 1.9.1 / Eigen 3.3.7 (Ubuntu 20.04 / ROS Noetic distro versions; an inference,
+// the reference pins nothing: package.xml:19-33).
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/vofod.h"
+
+namespace vo
+{
+
+struct Cloud
+{
+  std::vector<float> x, y, z;
+  std::vector<float> intensity;  // optional
+  size_t size() const { return x.size(); }
+};
+
+// ---------------------------------------------------------------- CropBox [3P]
+// pcl::CropBox<PointT>::applyFilter with identity transform: a point is inside iff
+// min <= p <= max on every axis (inclusive); negative=true keeps the points outside.
+// Non-finite points are dropped (PCL does so when !is_dense; a NaN also fails every
+// comparison, i.e. counts as "inside", and is dropped by the negative crop).
+inline bool crop_inside(const float p[3], const float mn[3], const float mx[3])
+{
+  if (p[0] < mn[0] || p[1] < mn[1] || p[2] < mn[2])
+    return false;
+  if (p[0] > mx[0] || p[1] > mx[1] || p[2] > mx[2])
+    return false;
+  return true;
+}
+
+// ------------------------------------------------------ transformPointCloud [3P]
+// pcl::detail::Transformer<float>::se3 (SSE form, the one an x86-64 build uses):
+//   out = c0*x + (c1*y + (c2*z + c3))   per row, mul and add rounded separately.
+// tf is row-major 3x4.
+inline void transform_point(const float tf[12], const float p[3], float out[3])
+{
+  for (int r = 0; r < 3; r++)
+  {
+    const float p0 = tf[4 * r + 0] * p[0];
+    const float p1 = tf[4 * r + 1] * p[1];
+    const float p2 = tf[4 * r + 2] * p[2];
+    out[r] = p0 + (p1 + (p2 + tf[4 * r + 3]));
+  }
+}
+
+// ------------------------------------------------- VoxelGridWeighted / Counted
+struct GridOut
+{
+  std::vector<vofod_point_xyzr> pts;
+  std::vector<uint32_t> keys;
+  vofod_grid_desc grid{};
+  int status = VOFOD_OK;
+};
+
+// voxel_grid_weighted.cpp:41-190 and voxel_grid_counted.cpp:49-196 (identical up to the
+// weight: weighted -> number of points in the voxel :181; counted -> count_if over the
+// *positional* range [first_index,last_index) of the input cloud :185-187).
+// [3P] pcl::VoxelGrid base: inverse_leaf_size_ = 1/leaf, min_points_per_voxel_ = 0,
+// pcl::getMinMax3D = plain min/max over the (finite) points.
+inline GridOut voxel_grid(const Cloud& in, const float leaf_in[3], const bool align_voxels, const float align_center[3], const bool counted,
+                          const float threshold)
+{
+  GridOut out;
+  const size_t n = in.size();
+  float leaf[3], inv[3];
+  for (int a = 0; a < 3; a++)
+  {
+    leaf[a] = leaf_in[a];
+    inv[a] = 1.0f / leaf[a];
+    out.grid.leaf[a] = leaf[a];
+  }
+  if (n == 0)
+    return out;
+
+  // getMinMax3D :58
+  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (size_t i = 0; i < n; i++)
+  {
+    const float p[3] = {in.x[i], in.y[i], in.z[i]};
+    for (int a = 0; a < 3; a++)
+    {
+      min_p[a] = std::min(min_p[a], p[a]);
+      max_p[a] = std::max(max_p[a], p[a]);
+    }
+  }
+
+  // overflow guard :61-69
+  const int64_t dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inv[0]) + 2;
+  const int64_t dy = static_cast<int64_t>((max_p[1] - min_p[1]) * inv[1]) + 2;
+  const int64_t dz = static_cast<int64_t>((max_p[2] - min_p[2]) * inv[2]) + 2;
+  if (dx * dy * dz > static_cast<int64_t>(std::numeric_limits<int32_t>::max()))
+  {
+    out.status = VOFOD_ERR_INDEX_OVERFLOW;
+    return out;
+  }
+
+  // :72-80
+  int min_b[3], max_b[3];
+  float offset[3];
+  for (int a = 0; a < 3; a++)
+  {
+    min_b[a] = static_cast<int>(std::floor(min_p[a] * inv[a]));
+    max_b[a] = static_cast<int>(std::floor(max_p[a] * inv[a]));
+    offset[a] = static_cast<float>(min_b[a]) * leaf[a];
+  }
+  // :81-106
+  if (align_voxels)
+  {
+    for (int a = 0; a < 3; a++)
+    {
+      float aco = std::fmod(align_center[a] - leaf[a] / 2, leaf[a]);
+      if (aco < 0)
+        aco += leaf[a];
+      offset[a] -= aco;
+      min_b[a] = static_cast<int>(std::floor(offset[a] * inv[a]));
+    }
+  }
+  // :109-113
+  int div_b[3];
+  for (int a = 0; a < 3; a++)
+    div_b[a] = max_b[a] - min_b[a] + 1;
+  const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+  for (int a = 0; a < 3; a++)
+  {
+    out.grid.offset[a] = offset[a];
+    out.grid.min_b[a] = min_b[a];
+    out.grid.div_b[a] = div_b[a];
+  }
+
+  // first pass :122-139
+  struct item
+  {
+    uint32_t idx;
+    uint32_t pt;
+    int ijk[3];
+  };
+  std::vector<item> index_vector;
+  index_vector.reserve(n);
+  for (size_t i = 0; i < n; i++)
+  {
+    item it;
+    it.ijk[0] = static_cast<int>(std::floor((in.x[i] - offset[0]) * inv[0]));
+    it.ijk[1] = static_cast<int>(std::floor((in.y[i] - offset[1]) * inv[1]));
+    it.ijk[2] = static_cast<int>(std::floor((in.z[i] - offset[2]) * inv[2]));
+    const int idx = it.ijk[0] * mul[0] + it.ijk[1] * mul[1] + it.ijk[2] * mul[2];
+    it.idx = static_cast<uint32_t>(idx);
+    it.pt = static_cast<uint32_t>(i);
+    index_vector.push_back(it);
+  }
+  // second pass :143 (std::sort in the reference; stable here so that the ijk read from the
+  // first element of a run is reproducible — equal keys carry equal ijk except when a
+  // rounding artefact pushes ijk0 to div_b[0], which aliases two cells onto one key)
+  std::stable_sort(index_vector.begin(), index_vector.end(), [](const item& a, const item& b) { return a.idx < b.idx; });
+
+  // third + fourth pass :147-188 / counted :179-194
+  size_t index = 0;
+  while (index < index_vector.size())
+  {
+    size_t i = index + 1;
+    while (i < index_vector.size() && index_vector[i].idx == index_vector[index].idx)
+      ++i;
+    const item& first = index_vector[index];
+    vofod_point_xyzr p;
+    p.x = (static_cast<float>(first.ijk[0]) + 0.5f) * leaf[0] + offset[0];
+    p.y = (static_cast<float>(first.ijk[1]) + 0.5f) * leaf[1] + offset[1];
+    p.z = (static_cast<float>(first.ijk[2]) + 0.5f) * leaf[2] + offset[2];
+    if (!counted)
+      p.range = static_cast<uint32_t>(i - index);
+    else
+    {
+      // voxel_grid_counted.cpp:185-187: positions [first_index,last_index) of the *input cloud*
+      uint32_t c = 0;
+      for (size_t pos = index; pos < i; pos++)
+        c += in.intensity[pos] > threshold;
+      p.range = c;
+    }
+    out.pts.push_back(p);
+    out.keys.push_back(first.idx);
+    index = i;
+  }
+  return out;
+}
+
+// -------------------------------------------- EuclideanClusterExtraction [3P]
+// pcl::extractEuclideanClusters + EuclideanClusterExtraction::extract with the defaults
+// clusterCloud leaves in place (vofod_nodelet.cpp:689-698: min 1, max INT_MAX):
+// connected components of { (a,b) : d2(a,b) < tol*tol }, d2 accumulated in float as
+// ((dx*dx + dy*dy) + dz*dz) (FLANN L2_Simple, RadiusResultSet keeps dist < radius).
+// Returned labels: label[i] = smallest member index of i's component.  The neighbour
+// search is a uniform hash grid of cell size tol (the reference uses a kd-tree; the set of
+// neighbours, hence the components, is the same).
+inline std::vector<uint32_t> euclidean_labels(const std::vector<vofod_point_xyzr>& pts, const float tolerance)
+{
+  const size_t n = pts.size();
+  std::vector<uint32_t> label(n, UINT32_MAX);
+  if (n == 0)
+    return label;
+  const float r2 = tolerance * tolerance;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  for (const auto& p : pts)
+  {
+    mn[0] = std::min(mn[0], p.x);
+    mn[1] = std::min(mn[1], p.y);
+    mn[2] = std::min(mn[2], p.z);
+  }
+  const double cell = std::max(static_cast<double>(tolerance), 1e-9) * 1.0001;  // strictly > tol so +-1 cell suffices
+  auto cellof = [&](const vofod_point_xyzr& p, int64_t c[3]) {
+    c[0] = static_cast<int64_t>(std::floor((static_cast<double>(p.x) - mn[0]) / cell));
+    c[1] = static_cast<int64_t>(std::floor((static_cast<double>(p.y) - mn[1]) / cell));
+    c[2] = static_cast<int64_t>(std::floor((static_cast<double>(p.z) - mn[2]) / cell));
+  };
+  auto keyof = [](const int64_t c[3]) { return (static_cast<uint64_t>(c[0] + 1) << 42) ^ (static_cast<uint64_t>(c[1] + 1) << 21) ^ static_cast<uint64_t>(c[2] + 1); };
+  std::unordered_map<uint64_t, std::vector<uint32_t>> cells;
+  cells.reserve(n);
+  for (size_t i = 0; i < n; i++)
+  {
+    int64_t c[3];
+    cellof(pts[i], c);
+    cells[keyof(c)].push_back(static_cast<uint32_t>(i));
+  }
+
+  std::vector<uint32_t> queue;
+  for (size_t seed = 0; seed < n; seed++)
+  {
+    if (label[seed] != UINT32_MAX)
+      continue;
+    queue.clear();
+    queue.push_back(static_cast<uint32_t>(seed));
+    label[seed] = static_cast<uint32_t>(seed);
+    for (size_t qi = 0; qi < queue.size(); qi++)
+    {
+      const vofod_point_xyzr& q = pts[queue[qi]];
+      int64_t c[3];
+      cellof(q, c);
+      for (int64_t cx = c[0] - 1; cx <= c[0] + 1; cx++)
+        for (int64_t cy = c[1] - 1; cy <= c[1] + 1; cy++)
+          for (int64_t cz = c[2] - 1; cz <= c[2] + 1; cz++)
+          {
+            const int64_t cc[3] = {cx, cy, cz};
+            const auto it = cells.find(keyof(cc));
+            if (it == cells.end())
+              continue;
+            for (const uint32_t j : it->second)
+            {
+              if (label[j] != UINT32_MAX)
+                continue;
+              const float ddx = q.x - pts[j].x, ddy = q.y - pts[j].y, ddz = q.z - pts[j].z;
+              float d2 = ddx * ddx;
+              d2 += ddy * ddy;
+              d2 += ddz * ddz;
+              if (d2 < r2)
+              {
+                label[j] = static_cast<uint32_t>(seed);
+                queue.push_back(j);
+              }
+            }
+          }
+    }
+  }
+  return label;
+}
+
+// Brute-force O(n^2) union-find over the same predicate; used by the tests to check
+// euclidean_labels itself.
+inline std::vector<uint32_t> euclidean_labels_bruteforce(const std::vector<vofod_point_xyzr>& pts, const float tolerance)
+{
+  const size_t n = pts.size();
+  std::vector<uint32_t> parent(n);
+  std::iota(parent.begin(), parent.end(), 0u);
+  std::function<uint32_t(uint32_t)> find = [&](uint32_t v) {
+    while (parent[v] != v)
+    {
+      parent[v] = parent[parent[v]];
+      v = parent[v];
+    }
+    return v;
+  };
+  const float r2 = tolerance * tolerance;
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = i + 1; j < n; j++)
+    {
+      const float ddx = pts[i].x - pts[j].x, ddy = pts[i].y - pts[j].y, ddz = pts[i].z - pts[j].z;
+      float d2 = ddx * ddx;
+      d2 += ddy * ddy;
+      d2 += ddz * ddz;
+      if (d2 < r2)
+      {
+        const uint32_t a = find(static_cast<uint32_t>(i)), b = find(static_cast<uint32_t>(j));
+        if (a != b)
+          parent[std::max(a, b)] = std::min(a, b);
+      }
+    }
+  std::vector<uint32_t> label(n);
+  for (size_t i = 0; i < n; i++)
+    label[i] = find(static_cast<uint32_t>(i));
+  return label;
+}
+
+struct Cluster
+{
+  std::vector<int> indices;  // ascending (extract_clusters sorts them)
+};
+
+// Canonical cluster order: size descending (EuclideanClusterExtraction::extract's reverse
+// sort by size), ties by smallest member (what libstdc++'s insertion sort yields for <= 16
+// clusters; unspecified by the reference beyond that — SURVEY H3).
+inline std::vector<Cluster> clusters_from_labels(const std::vector<uint32_t>& label)
+{
+  std::unordered_map<uint32_t, size_t> slot;
+  std::vector<Cluster> cl;
+  for (size_t i = 0; i < label.size(); i++)
+  {
+    auto it = slot.find(label[i]);
+    if (it == slot.end())
+    {
+      it = slot.emplace(label[i], cl.size()).first;
+      cl.emplace_back();
+    }
+    cl[it->second].indices.push_back(static_cast<int>(i));
+  }
+  std::stable_sort(cl.begin(), cl.end(), [](const Cluster& a, const Cluster& b) {
+    if (a.indices.size() != b.indices.size())
+      return a.indices.size() > b.indices.size();
+    return a.indices.front() < b.indices.front();
+  });
+  return cl;
+}
+
+// ------------------------------------------- MomentOfInertiaEstimation [3P]
+struct Boxes
+{
+  float aabb_min[3], aabb_max[3];
+  float obb_min[3], obb_max[3], obb_center[3];
+  float axes[3][3];  // major, middle, minor
+  float eig[3];
+};
+
+// Symmetric 3x3 eigen-decomposition (cyclic Jacobi, double).  The reference reaches its
+// eigenvectors through Eigen::EigenSolver<Matrix3f> (general real solver); any correct
+// solver gives the same eigen-spaces, and the quantities the hot path consumes (OBB centre,
+// OBB diagonal) do not depend on the basis chosen inside a degenerate eigen-space whenever
+// the projections on it are symmetric or zero — parity there is by tolerance.
+inline void jacobi_eigen3(const double A_in[3][3], double w[3], double V[3][3])
+{
+  double A[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+    {
+      A[i][j] = A_in[i][j];
+      V[i][j] = i == j;
+    }
+  for (int sweep = 0; sweep < 64; sweep++)
+  {
+    const double offd = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+    if (offd < 1e-300)
+      break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++)
+      {
+        if (std::fabs(A[p][q]) < 1e-300)
+          continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; k++)
+        {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++)
+        {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++)
+        {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 3; i++)
+    w[i] = A[i][i];
+}
+
+// moment_of_inertia_estimation.hpp: computeMeanValue, computeCovarianceMatrix (normalised by
+// point_mass_ = 1/n^2), computeEigenVectors (sort major >= middle >= minor, right-handed),
+// computeOBB (obb max initialised to FLT_MIN as PCL does, position = mean + R*shift).
+inline Boxes moie(const std::vector<vofod_point_xyzr>& pts, const std::vector<int>& indices)
+{
+  Boxes b;
+  const size_t n = indices.size();
+  float mean[3] = {0, 0, 0};
+  for (int a = 0; a < 3; a++)
+  {
+    b.aabb_min[a] = FLT_MAX;
+    b.aabb_max[a] = -FLT_MAX;
+  }
+  for (const int i : indices)
+  {
+    const float p[3] = {pts[i].x, pts[i].y, pts[i].z};
+    for (int a = 0; a < 3; a++)
+    {
+      mean[a] += p[a];
+      if (p[a] <= b.aabb_min[a])
+        b.aabb_min[a] = p[a];
+      if (p[a] >= b.aabb_max[a])
+        b.aabb_max[a] = p[a];
+    }
+  }
+  const unsigned np = n == 0 ? 1u : static_cast<unsigned>(n);
+  for (int a = 0; a < 3; a++)
+    mean[a] /= static_cast<float>(np);
+
+  float cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (const int i : indices)
+  {
+    const float c[3] = {pts[i].x - mean[0], pts[i].y - mean[1], pts[i].z - mean[2]};
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++)
+        cov[r][cc] += c[r] * c[cc];
+  }
+  const float point_mass = 1.0f / static_cast<float>(n * n);
+  double A[3][3], w[3], V[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++)
+    {
+      cov[r][cc] *= point_mass;
+      A[r][cc] = cov[r][cc];
+    }
+  jacobi_eigen3(A, w, V);
+  int major = 0, middle = 1, minor = 2;
+  if (w[major] < w[middle])
+    std::swap(major, middle);
+  if (w[major] < w[minor])
+    std::swap(major, minor);
+  if (w[middle] < w[minor])
+    std::swap(minor, middle);
+  const int order[3] = {major, middle, minor};
+  for (int k = 0; k < 3; k++)
+  {
+    b.eig[k] = static_cast<float>(w[order[k]]);
+    float v[3] = {static_cast<float>(V[0][order[k]]), static_cast<float>(V[1][order[k]]), static_cast<float>(V[2][order[k]])};
+    const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    for (int a = 0; a < 3; a++)
+      b.axes[k][a] = v[a] / nrm;
+  }
+  {
+    const float* M = b.axes[0];
+    const float* D = b.axes[1];
+    const float* N = b.axes[2];
+    const float cr[3] = {D[1] * N[2] - D[2] * N[1], D[2] * N[0] - D[0] * N[2], D[0] * N[1] - D[1] * N[0]};
+    const float det = M[0] * cr[0] + M[1] * cr[1] + M[2] * cr[2];
+    if (det <= 0.0f)
+      for (int a = 0; a < 3; a++)
+        b.axes[0][a] = -b.axes[0][a];
+  }
+  for (int a = 0; a < 3; a++)
+  {
+    b.obb_min[a] = FLT_MAX;
+    b.obb_max[a] = FLT_MIN;  // sic (PCL)
+  }
+  for (const int i : indices)
+  {
+    const float c[3] = {pts[i].x - mean[0], pts[i].y - mean[1], pts[i].z - mean[2]};
+    for (int k = 0; k < 3; k++)
+    {
+      const float proj = c[0] * b.axes[k][0] + c[1] * b.axes[k][1] + c[2] * b.axes[k][2];
+      if (proj <= b.obb_min[k])
+        b.obb_min[k] = proj;
+      if (proj >= b.obb_max[k])
+        b.obb_max[k] = proj;
+    }
+  }
+  float shift[3];
+  for (int k = 0; k < 3; k++)
+  {
+    shift[k] = (b.obb_max[k] + b.obb_min[k]) / 2.0f;
+    b.obb_min[k] -= shift[k];
+    b.obb_max[k] -= shift[k];
+  }
+  for (int a = 0; a < 3; a++)
+    b.obb_center[a] = mean[a] + (b.axes[0][a] * shift[0] + b.axes[1][a] * shift[1] + b.axes[2][a] * shift[2]);
+  return b;
+}
+
+// ---------------------------------------------------------- sensor LUT (sim)
+// initialize_sensor_lut_simulation, vofod_nodelet.cpp:374-420
+inline void sim_lut(const int w, const int h, const float vfov, float* directions)
+{
+  const double minAngle = 0.0, maxAngle = 2.0 * M_PI;
+  const double verticalMinAngle = -vfov / 2.0, verticalMaxAngle = vfov / 2.0;
+  const double yAngle_step = (maxAngle - minAngle) / (w - 1);
+  const double pAngle_step = (verticalMaxAngle - verticalMinAngle) / (h - 1);
+  for (int row = 0; row < h; row++)
+    for (int col = 0; col < w; col++)
+    {
+      const double yAngle = col * yAngle_step + minAngle;
+      const double pAngle = row * pAngle_step + verticalMinAngle;
+      float* d = directions + 3 * (static_cast<size_t>(row) * w + col);
+      d[0] = static_cast<float>(std::cos(pAngle) * std::cos(yAngle));
+      d[1] = static_cast<float>(std::cos(pAngle) * std::sin(yAngle));
+      d[2] = static_cast<float>(std::sin(pAngle));
+    }
+}
+
+}  // namespace vo
