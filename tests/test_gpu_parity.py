@@ -1,0 +1,224 @@
+"""GPU parity tests: the HIP path (through its C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (north_star): bit-exact voxel indices, weights, centres, cluster membership, close/far flags, classes
+and map contents after integer/byte-exact stages; stated tolerances on OBB-derived positions, confidences
+and on everything downstream of the float-atomic raycast accumulation.
+"""
+import numpy as np
+import pytest
+
+from vofod_amd import capi, synth
+from vofod_amd.detector import cluster, voxel_grid_counted, voxel_grid_weighted
+
+from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair, sync_maps
+
+pytestmark = pytest.mark.gpu
+
+
+def _world_cloud(seed, sensor="os1-128"):
+    scene = synth.make_scene(seed)
+    tf = synth.make_pose(seed)
+    s = synth.make_scan(scene, tf, sensor, seed=seed)
+    ok = s.range > 0
+    p = np.stack([s.x[ok], s.y[ok], s.z[ok]], axis=1).astype(np.float64)
+    q = (p @ tf[:, :3].astype(np.float64).T + tf[:, 3]).astype(np.float32)
+    return q
+
+
+@pytest.mark.parametrize("leaf", [0.5, 0.25, 0.1])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_voxel_grid_weighted_bit_exact(oracle, hip, leaf, seed):
+    ref, dev = make_pair(oracle, hip)
+    q = _world_cloud(seed)
+    for align in (None, (-19.75, -29.75, -1.0), (0.37, -0.11, 0.05)):
+        a = voxel_grid_weighted(oracle, q[:, 0], q[:, 1], q[:, 2], leaf, align)
+        b = voxel_grid_weighted(hip, q[:, 0], q[:, 1], q[:, 2], leaf, align, handle=dev.h)
+        np.testing.assert_array_equal(b[1], a[1])
+        np.testing.assert_array_equal(b[0].view(np.uint32), a[0].view(np.uint32))
+        for f in ("leaf", "offset", "min_b", "div_b"):
+            assert list(getattr(b[2], f)) == list(getattr(a[2], f)), f
+        assert int(a[0]["range"].sum()) == q.shape[0]
+
+
+def test_voxel_grid_edge_cases(oracle, hip):
+    ref, dev = make_pair(oracle, hip)
+    e = np.zeros(0, dtype=np.float32)
+    out, keys, grid, st = voxel_grid_weighted(hip, e, e, e, 0.5, handle=dev.h)
+    assert st == capi.OK and out.size == 0
+    one = np.float32([[1.3, -2.2, 0.7]])
+    a = voxel_grid_weighted(oracle, one[:, 0], one[:, 1], one[:, 2], 0.5)
+    b = voxel_grid_weighted(hip, one[:, 0], one[:, 1], one[:, 2], 0.5, handle=dev.h)
+    np.testing.assert_array_equal(b[0].view(np.uint32), a[0].view(np.uint32))
+    x = np.float32([0, 1e6])
+    out, keys, grid, st = voxel_grid_weighted(hip, x, x, x, 0.01, handle=dev.h, allow=(capi.ERR_INDEX_OVERFLOW,))
+    assert st == capi.ERR_INDEX_OVERFLOW and out.size == 0
+    # many duplicates of one point: weight saturates nothing, count is exact
+    d = np.full(100000, 3.21, dtype=np.float32)
+    out, keys, grid, st = voxel_grid_weighted(hip, d, d, d, 0.5, handle=dev.h)
+    assert out.size == 1 and out["range"][0] == 100000
+
+
+@pytest.mark.parametrize("leaf,thr", [(1.0, -0.1), (3.0, -0.1), (2.0, -100.0)])
+def test_voxel_grid_counted_positional_quirk(oracle, hip, leaf, thr):
+    ref, dev = make_pair(oracle, hip)
+    rng = np.random.default_rng(5)
+    # an index cloud in voxelsAsVoxelPC order (x outer, z inner) with map values as intensity
+    occ = rng.random((60, 50, 20)) < 0.08
+    xs, ys, zs = np.nonzero(occ)
+    inten = rng.choice(np.float32([0.0, -50.0, -200.0, np.inf]), size=xs.size)
+    a = voxel_grid_counted(oracle, xs, ys, zs, inten, leaf, thr)
+    b = voxel_grid_counted(hip, xs, ys, zs, inten, leaf, thr, handle=dev.h)
+    np.testing.assert_array_equal(b[1], a[1])
+    np.testing.assert_array_equal(b[0].view(np.uint32), a[0].view(np.uint32))
+    assert int(b[0]["range"].sum()) == int((inten > thr).sum())
+
+
+@pytest.mark.parametrize("leaf,tol", [(0.5, 1.5), (0.25, 1.5), (0.5, 0.7), (0.1, 1.5), (1.0, 2.0), (3.0, 4.0)])
+def test_cluster_membership_bit_exact(oracle, hip, leaf, tol):
+    ref, dev = make_pair(oracle, hip)
+    q = _world_cloud(3)
+    if leaf >= 1.0:
+        q = q * 4.0
+    pts, keys, grid, _ = voxel_grid_weighted(oracle, q[:, 0], q[:, 1], q[:, 2], leaf, (-19.75, -29.75, -1.0))
+    la, na = cluster(oracle, pts, keys, grid, tol)
+    lb, nb = cluster(hip, pts, keys, grid, tol, handle=dev.h)
+    np.testing.assert_array_equal(lb, la)
+    assert na == nb
+
+
+def test_cluster_tolerance_boundary(oracle, hip):
+    # lattice chains exactly on the tolerance boundary: 3 voxels apart at tol 1.5 / leaf 0.5
+    ref, dev = make_pair(oracle, hip)
+    x = np.float32([0.25, 1.75, 3.25, 4.25, 10.25, 10.25, 10.25])
+    y = np.float32([0.25, 0.25, 0.25, 0.25, 0.25, 1.25, 2.75])
+    z = np.float32([0.25] * 7)
+    pts, keys, grid, _ = voxel_grid_weighted(oracle, x, y, z, 0.5)
+    la, na = cluster(oracle, pts, keys, grid, 1.5)
+    lb, nb = cluster(hip, pts, keys, grid, 1.5, handle=dev.h)
+    np.testing.assert_array_equal(lb, la)
+    assert na == 5  # {0},{1},{2,3},{4,5},{6}
+    # far from the origin the centres are not exact multiples any more: evaluate in float like FLANN does
+    off = np.float32(91.3)
+    pts2, keys2, grid2, _ = voxel_grid_weighted(oracle, x + off, y + off, z + off, 0.5, (0.05, 0.05, 0.05))
+    la, _ = cluster(oracle, pts2, keys2, grid2, 1.5)
+    lb, _ = cluster(hip, pts2, keys2, grid2, 1.5, handle=dev.h)
+    np.testing.assert_array_equal(lb, la)
+
+
+def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2):
+    """Step both detectors through the same scans; every step starts from identical maps."""
+    n_det = 0
+    for k, s in enumerate(scans):
+        dr, gr = ref.process_scan(s.scan, s.tf, flags=flags, debug=True)
+        dh, gh = dev.process_scan(s.scan, s.tf, flags=flags, debug=True)
+        assert_scan_debug_equal(gr, gh)
+        assert_detections_equal(dr, dh)
+        n_det += len(dr)
+        np.testing.assert_array_equal(dev.read_map(capi.MAP_VOXELS), ref.read_map(capi.MAP_VOXELS))
+        np.testing.assert_array_equal(dev.read_map(capi.MAP_FLAGS), ref.read_map(capi.MAP_FLAGS))
+        # raycast of this scan, applied after the next detection iteration (vofod_nodelet.cpp:1530-1539)
+        if k + 1 < len(scans):
+            assert ref.raycast_begin(s.scan, s.tf) == dev.raycast_begin(s.scan, s.tf) == capi.OK
+            ra, rb = ref.read_map(capi.MAP_RAYCAST), dev.read_map(capi.MAP_RAYCAST)
+            # tolerance: float-atomic accumulation order
+            np.testing.assert_allclose(rb, ra, rtol=2e-5, atol=2e-6)
+            nxt = scans[k + 1]
+            dr, gr = ref.process_scan(nxt.scan, nxt.tf, debug=True)
+            dh, gh = dev.process_scan(nxt.scan, nxt.tf, debug=True)
+            assert_scan_debug_equal(gr, gh)
+            assert_detections_equal(dr, dh)
+            assert ref.raycast_finish() == dev.raycast_finish() == capi.OK
+            ma, mb = ref.read_map(capi.MAP_VOXELS), dev.read_map(capi.MAP_VOXELS)
+            fin = np.isfinite(ma)
+            np.testing.assert_array_equal(np.isfinite(mb), fin)
+            np.testing.assert_allclose(mb[fin], ma[fin], rtol=1e-4, atol=1e-3)
+            assert not dev.read_map(capi.MAP_FLAGS).any() and not ref.read_map(capi.MAP_FLAGS).any()
+            sync_maps(ref, dev)  # the next bit-exact stage starts from identical state again
+        if sep_every and k % sep_every == 1:
+            (sa, la), (sb, lb) = ref.sepclusters_begin(allow=(capi.ERR_EMPTY,)), dev.sepclusters_begin(allow=(capi.ERR_EMPTY,))
+            assert (sa, la) == (sb, lb)
+            if sa == capi.OK and la:
+                assert ref.sepclusters_finish() == dev.sepclusters_finish() == capi.OK
+                np.testing.assert_array_equal(dev.read_map(capi.MAP_VOXELS), ref.read_map(capi.MAP_VOXELS))
+    return n_det
+
+
+@pytest.mark.parametrize("sensor,vs", [("os1-16", 0.5), ("os1-128", 0.5), ("os1-128", 0.25)])
+def test_process_scan_sequence_parity(oracle, hip, sensor, vs):
+    ref, dev = make_pair(oracle, hip, sensor, vs)
+    scene = synth.make_scene(11, n_targets=2)
+    scans = synth.scan_sequence(scene, sensor, 5, seed0=100)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    _run_sequence(ref, dev, scans)
+    assert dev.status().detection_its == ref.status().detection_its
+
+
+def test_process_scan_with_apriori_map_detects(oracle, hip):
+    """config 3 shape: apriori (+inf) background, latches set, classification + flood fill active."""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5)
+    scene = synth.make_scene(21, n_targets=3)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+    np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+    scans = synth.scan_sequence(scene, "os1-128", 4, seed0=300)
+    n_det = _run_sequence(ref, dev, scans, sep_every=2)
+    assert n_det > 0  # the floating boxes are found, identically on both sides
+
+
+def test_no_map_update_and_batch_parity(oracle, hip):
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=4)
+    scene = synth.make_scene(31, n_targets=2)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+    before = dev.read_map()
+    scans = synth.scan_sequence(scene, "os1-128", 6, seed0=500)
+    tfs = np.stack([s.tf for s in scans])
+    da, pa, ga = ref.process_batch([s.scan for s in scans], tfs, debug=True)
+    db, pb, gb = dev.process_batch([s.scan for s in scans], tfs, debug=True)  # 6 frames > max_batch 4: two launch groups
+    np.testing.assert_array_equal(pb, pa)
+    assert_detections_equal(da, db)
+    for x, y in zip(ga, gb):
+        assert_scan_debug_equal(x, y)
+    np.testing.assert_array_equal(dev.read_map(), before)  # read-only map
+    assert dev.status().detection_its == 0
+
+
+def test_error_paths(oracle, hip):
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
+    scene = synth.make_scene(1)
+    s = synth.scan_sequence(scene, "os1-16", 1)[0]
+    bad = synth.make_scan(scene, s.tf, "os1-128", seed=0)
+    for d in (ref, dev):
+        with pytest.raises(Exception):
+            d.process_scan(bad.scan, bad.tf)  # size mismatch (vofod_nodelet.cpp:895-899)
+        assert d.raycast_finish(allow=(capi.ERR_NOT_PENDING,)) == capi.ERR_NOT_PENDING
+        assert d.raycast_begin(s.scan, s.tf) == capi.OK
+        assert d.raycast_finish(allow=(capi.ERR_RAYCAST_NO_DETECTION,)) == capi.ERR_RAYCAST_NO_DETECTION  # :1531-1537
+        # an all-no-return scan: nothing survives the exclude box, nothing is cast
+        empty = synth.make_scan(synth.Scene((0, 0, 0, 0), np.zeros((0, 6)), 0), s.tf, "os1-16", seed=0)
+        dets, dbg = d.process_scan(empty.scan, empty.tf, debug=True)
+        assert len(dets) == 0 and len(dbg["weighted"]) == 0 and len(dbg["clusters"]) == 0
+        d.set_dynamic_params(raycast__pause=1)
+        assert d.raycast_begin(s.scan, s.tf, allow=(capi.ERR_PAUSED,)) == capi.ERR_PAUSED
+        d.set_dynamic_params(raycast__pause=0)
+        # sensor outside the map (vofod_nodelet.cpp:1432, 1523-1526)
+        tf_out = s.tf.copy()
+        tf_out[2, 3] = 500.0
+        assert d.raycast_begin(s.scan, tf_out, allow=(capi.ERR_SENSOR_OUTSIDE_MAP,)) == capi.ERR_SENSOR_OUTSIDE_MAP
+        d.process_scan(s.scan, s.tf)
+        assert d.raycast_finish(allow=(capi.ERR_RAYCAST_EMPTY,)) == capi.ERR_RAYCAST_EMPTY
+
+
+def test_old_raycast_rule(oracle, hip):
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.5, raycast__new_update_rule=0, raycast__weight_coefficient=0.5)
+    scene = synth.make_scene(2)
+    scans = synth.scan_sequence(scene, "os1-16", 2, seed0=7)
+    for d in (ref, dev):
+        d.process_scan(scans[0].scan, scans[0].tf)
+        d.raycast_begin(scans[0].scan, scans[0].tf)
+        d.process_scan(scans[1].scan, scans[1].tf)
+        assert d.raycast_finish() == capi.OK
+    np.testing.assert_allclose(dev.read_map(), ref.read_map(), rtol=1e-4, atol=1e-3)

@@ -1,0 +1,235 @@
+// Host-side classification tail of the product (C++): classify_cluster (vofod_nodelet.cpp:1648-1730)
+// and extractDetections (:834-879) for the few far clusters that survive the device-side gates.
+// It works on small sub-boxes of the voxel map read back from the device.  This is
+// product code: it never touches oracle/.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <unordered_set>
+#include <vector>
+
+#include "common.h"
+
+namespace vt
+{
+
+// VoxelMap geometry (voxel_map.cpp:592-613) on the host, same float expressions as the kernels.
+struct Geom
+{
+  float off[3];
+  float vs, vs_inv;
+  int s[3];
+  void coordToIdx(const float p[3], int o[3]) const
+  {
+    for (int a = 0; a < 3; a++)
+      o[a] = static_cast<int>(std::floor((p[a] - off[a]) * vs_inv));
+  }
+  void idxToCoord(const int i[3], float c[3]) const
+  {
+    for (int a = 0; a < 3; a++)
+      c[a] = (i[a] + 0.5f) * vs + off[a];
+  }
+  bool inLimits(const int i[3]) const { return i[0] >= 0 && i[0] < s[0] && i[1] >= 0 && i[1] < s[1] && i[2] >= 0 && i[2] < s[2]; }
+  uint64_t lin(const int i[3]) const { return (static_cast<uint64_t>(i[2]) * s[1] + i[1]) * s[0] + i[0]; }
+};
+
+// A dense host copy of the map cells [lo, lo+n) (x fastest), with this scan's pending frontier writes applied.
+struct Box
+{
+  int lo[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+  std::vector<float> v;
+  bool has(const int i[3]) const { return i[0] >= lo[0] && i[0] < lo[0] + n[0] && i[1] >= lo[1] && i[1] < lo[1] + n[1] && i[2] >= lo[2] && i[2] < lo[2] + n[2]; }
+  size_t at(const int i[3]) const { return (static_cast<size_t>(i[2] - lo[2]) * n[1] + (i[1] - lo[1])) * n[0] + (i[0] - lo[0]); }
+};
+
+struct Member
+{
+  uint32_t v;
+  float p[3];
+  uint32_t count;
+};
+
+struct Boxes
+{
+  float aabb_min[3], aabb_max[3];
+  float obb_min[3], obb_max[3], obb_center[3];
+};
+
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations
+inline void eig3(double a[3][3], double w[3], double v[3][3])
+{
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int it = 0; it < 60; it++)
+  {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-280)
+      break;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 3; q++)
+      {
+        if (a[p][q] == 0.0)
+          continue;
+        const double tau = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < 3; k++)
+        {
+          const double x = a[k][p], y = a[k][q];
+          a[k][p] = c * x - s * y;
+          a[k][q] = s * x + c * y;
+        }
+        for (int k = 0; k < 3; k++)
+        {
+          const double x = a[p][k], y = a[q][k];
+          a[p][k] = c * x - s * y;
+          a[q][k] = s * x + c * y;
+        }
+        for (int k = 0; k < 3; k++)
+        {
+          const double x = v[k][p], y = v[k][q];
+          v[k][p] = c * x - s * y;
+          v[k][q] = s * x + c * y;
+        }
+      }
+  }
+  for (int i = 0; i < 3; i++)
+    w[i] = a[i][i];
+}
+
+// [3P] pcl::MomentOfInertiaEstimation: mean, covariance/n^2, principal axes (major >= middle >= minor,
+// right-handed), AABB and OBB (centre = mean + R*shift).  Members are in ascending index order.
+inline Boxes boxes_of(const std::vector<Member>& m)
+{
+  Boxes b;
+  float mean[3] = {0, 0, 0};
+  for (int a = 0; a < 3; a++)
+  {
+    b.aabb_min[a] = FLT_MAX;
+    b.aabb_max[a] = -FLT_MAX;
+  }
+  for (const Member& e : m)
+    for (int a = 0; a < 3; a++)
+    {
+      mean[a] += e.p[a];
+      b.aabb_min[a] = std::min(b.aabb_min[a], e.p[a]);
+      b.aabb_max[a] = std::max(b.aabb_max[a], e.p[a]);
+    }
+  const float nf = static_cast<float>(static_cast<unsigned>(m.size()));
+  for (int a = 0; a < 3; a++)
+    mean[a] /= nf;
+  float cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (const Member& e : m)
+  {
+    const float c[3] = {e.p[0] - mean[0], e.p[1] - mean[1], e.p[2] - mean[2]};
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++)
+        cov[r][q] += c[r] * c[q];
+  }
+  const float mass = 1.0f / static_cast<float>(m.size() * m.size());
+  double A[3][3], w[3], V[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 3; q++)
+      A[r][q] = cov[r][q] * mass;
+  eig3(A, w, V);
+  int ord[3] = {0, 1, 2};
+  if (w[ord[0]] < w[ord[1]])
+    std::swap(ord[0], ord[1]);
+  if (w[ord[0]] < w[ord[2]])
+    std::swap(ord[0], ord[2]);
+  if (w[ord[1]] < w[ord[2]])
+    std::swap(ord[1], ord[2]);
+  float ax[3][3];
+  for (int k = 0; k < 3; k++)
+  {
+    float u[3] = {static_cast<float>(V[0][ord[k]]), static_cast<float>(V[1][ord[k]]), static_cast<float>(V[2][ord[k]])};
+    const float nn = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (int a = 0; a < 3; a++)
+      ax[k][a] = u[a] / nn;
+  }
+  const float cr[3] = {ax[1][1] * ax[2][2] - ax[1][2] * ax[2][1], ax[1][2] * ax[2][0] - ax[1][0] * ax[2][2], ax[1][0] * ax[2][1] - ax[1][1] * ax[2][0]};
+  if (ax[0][0] * cr[0] + ax[0][1] * cr[1] + ax[0][2] * cr[2] <= 0.0f)
+    for (int a = 0; a < 3; a++)
+      ax[0][a] = -ax[0][a];
+  for (int k = 0; k < 3; k++)
+  {
+    b.obb_min[k] = FLT_MAX;
+    b.obb_max[k] = FLT_MIN;  // PCL initialises the OBB maximum with numeric_limits<float>::min()
+  }
+  for (const Member& e : m)
+  {
+    const float c[3] = {e.p[0] - mean[0], e.p[1] - mean[1], e.p[2] - mean[2]};
+    for (int k = 0; k < 3; k++)
+    {
+      const float pr = c[0] * ax[k][0] + c[1] * ax[k][1] + c[2] * ax[k][2];
+      if (pr <= b.obb_min[k])
+        b.obb_min[k] = pr;
+      if (pr >= b.obb_max[k])
+        b.obb_max[k] = pr;
+    }
+  }
+  float shift[3];
+  for (int k = 0; k < 3; k++)
+  {
+    shift[k] = (b.obb_max[k] + b.obb_min[k]) / 2.0f;
+    b.obb_min[k] -= shift[k];
+    b.obb_max[k] -= shift[k];
+  }
+  for (int a = 0; a < 3; a++)
+    b.obb_center[a] = mean[a] + (ax[0][a] * shift[0] + ax[1][a] * shift[1] + ax[2][a] * shift[2]);
+  return b;
+}
+
+// VoxelMap::exploreToGround (voxel_map.cpp:402-488) as a flood fill over a read-back box.  The
+// reference's DFS returns "connected" iff some reachable voxel satisfies one of its exit tests, and
+// otherwise the set of reachable unknown voxels, both independent of the visiting order,
+// so a visited-on-push fill yields the same answer.  `box` must cover the Manhattan ball of radius
+// max_voxel_dist around the start voxel clipped to the map.
+inline bool explore_to_ground(const Geom& g, const Box& box, const float p[3], float unknown_thr, float ground_thr, float max_voxel_dist,
+                              std::vector<uint64_t>& explored_unknown)
+{
+  explored_unknown.clear();
+  int o[3];
+  g.coordToIdx(p, o);
+  for (int a = 0; a < 3; a++)
+    if (o[a] <= 0 || o[a] >= g.s[a] - 1)
+      return true;
+  std::unordered_set<uint64_t> seen;
+  std::vector<std::array<int, 3>> stack;
+  stack.push_back({o[0], o[1], o[2]});
+  seen.insert(g.lin(o));
+  while (!stack.empty())
+  {
+    const std::array<int, 3> cur = stack.back();
+    stack.pop_back();
+    const int ci[3] = {cur[0], cur[1], cur[2]};
+    const float val = box.v[box.at(ci)];
+    if (val > ground_thr)
+      return true;
+    if (!(val > unknown_thr))
+      continue;
+    explored_unknown.push_back(g.lin(ci));
+    const int md = std::abs(ci[0] - o[0]) + std::abs(ci[1] - o[1]) + std::abs(ci[2] - o[2]);
+    if (static_cast<float>(md) == max_voxel_dist - 1)
+      return true;
+    for (int a = 0; a < 3; a++)
+      for (int s = 1; s >= -1; s -= 2)
+      {
+        int t[3] = {ci[0], ci[1], ci[2]};
+        t[a] += s;
+        if (t[a] < 0 || t[a] > g.s[a] - 1)
+          continue;
+        const int tmd = std::abs(t[0] - o[0]) + std::abs(t[1] - o[1]) + std::abs(t[2] - o[2]);
+        if (!(static_cast<float>(tmd) <= max_voxel_dist))
+          continue;
+        if (seen.insert(g.lin(t)).second)
+          stack.push_back({t[0], t[1], t[2]});
+      }
+  }
+  return false;
+}
+
+}  // namespace vt

@@ -1,0 +1,387 @@
+// Euclidean clustering (K7), close/far split (K8, K9) and voxel-map update (K10) kernels for gfx950.
+//
+// Clustering replaces pcl::EuclideanClusterExtraction (kd-tree radius BFS) called from clusterCloud
+// (vofod_nodelet.cpp:689-698).  The points are centres of an integer lattice, so the neighbours of a
+// voxel within the tolerance are the set bits of the frame's occupancy bitmap inside a fixed stencil.
+// The stencil is a host-built table of (dj,dk) rows; a row's x-run is fetched as one <=63-bit window
+// out of two bitmap words, neighbour ids come from the word-prefix array, and components are merged
+// with a lock-free union-find that always hooks the larger root under the smaller one, so the final
+// label of a component is its smallest member — the same canonical label the oracle uses.
+// Offsets whose nominal distance sits on the tolerance boundary are decided by the float expression
+// FLANN evaluates (((dx*dx)+dy*dy)+dz*dz < tol*tol) on the actual centres.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_voxelize.h"
+
+namespace vk
+{
+
+__device__ __forceinline__ uint32_t uf_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void uf_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// representative with intermediate pointer jumping (parents only ever decrease)
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t v)
+{
+  uint32_t curr = uf_ld(&parent[v]);
+  if (curr != v)
+  {
+    uint32_t prev = v, next;
+    while (curr > (next = uf_ld(&parent[curr])))
+    {
+      uf_st(&parent[prev], next);
+      prev = curr;
+      curr = next;
+    }
+  }
+  return curr;
+}
+
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b)
+{
+  uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
+  while (ra != rb)
+  {
+    if (ra < rb)
+    {
+      const uint32_t t = ra;
+      ra = rb;
+      rb = t;
+    }
+    // ra > rb: hook ra under rb if ra is still a root
+    const uint32_t old = atomicCAS(&parent[ra], ra, rb);
+    if (old == ra)
+      break;
+    ra = old;  // somebody re-parented ra meanwhile: climb and retry
+  }
+}
+
+__global__ __launch_bounds__(256) void k_union(const GridParams g, const ClusterParams cp, const StencilRow* __restrict__ rows, const FrameHdr* hdrs,
+                                               const unsigned long long* bitmaps, const uint32_t* wprefix_all, VoxelArrays va_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= h.V)
+    return;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const int dx = h.div_b[0], dy = h.div_b[1], dz = h.div_b[2];
+  const uint32_t key = va.key[v];
+  const int k = key / (dx * dy);
+  const int rem = key - k * dx * dy;
+  const int j = rem / dx;
+  const int i = rem - j * dx;
+  float4 pv = va.pts[v];
+  const unsigned long long gapmask = cp.row_gap >= 0 ? ((2ull << cp.row_gap) - 1ull) : 1ull;
+
+  for (int r = 0; r < cp.n_rows; r++)
+  {
+    const StencilRow row = rows[r];
+    const int jj = j + row.dj, kk = k + row.dk;
+    if (jj < 0 || jj >= dy || kk >= dz)
+      continue;
+    const bool own_row = (row.dj == 0 && row.dk == 0);
+    const int lo = own_row ? i + 1 : max(i - row.r_max, 0);
+    const int hi = min(i + row.r_max, dx - 1);
+    if (lo > hi)
+      continue;
+    const uint32_t L = static_cast<uint32_t>((kk * dy + jj) * dx + lo);
+    const int nbits = hi - lo + 1;
+    const uint32_t wi = L >> 6;
+    const int sh = L & 63;
+    const unsigned long long w0 = bm[wi];
+    const unsigned long long w1 = bm[wi + 1];  // guard words are allocated past n_words
+    unsigned long long win = (w0 >> sh) | (sh ? (w1 << (64 - sh)) : 0ull);
+    win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+    if (!win)
+      continue;
+    const unsigned long long win0 = win;
+    const uint32_t pre = wprefix[wi] + __popcll(w0 & ((1ull << sh) - 1ull));
+    while (win)
+    {
+      const int t = __ffsll(static_cast<long long>(win)) - 1;
+      const int adi = abs(lo + t - i);
+      const uint32_t nb = pre + __popcll(win0 & ((1ull << t) - 1ull));
+      bool ok = adi <= row.r_sure;
+      if (!ok && ((row.amb >> adi) & 1u))
+      {
+        const float4 pn = va.pts[nb];
+        const float ddx = __fsub_rn(pv.x, pn.x), ddy = __fsub_rn(pv.y, pn.y), ddz = __fsub_rn(pv.z, pn.z);
+        float d2 = __fmul_rn(ddx, ddx);
+        d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
+        d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
+        ok = d2 < cp.r2;
+      }
+      if (ok)
+      {
+        uf_union(va.parent, v, nb);
+        // bits within the sure in-row gap of this neighbour are linked to it by their own row-(0,0) pass
+        win &= ~(gapmask << t);
+      }
+      else
+        win &= win - 1;
+    }
+  }
+}
+
+// Flatten the forest (label = root = smallest member) and accumulate per-cluster size and lattice AABB.
+__global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = v < h.V;
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  uint32_t* labels = labels_all + static_cast<size_t>(blockIdx.y) * g.vox_cap;
+  uint32_t root = 0xffffffffu;
+  int ijk[3] = {0, 0, 0};
+  if (active)
+  {
+    root = v;
+    uint32_t p;
+    while ((p = va.parent[root]) != root)
+      root = p;
+    labels[v] = root;
+    const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+    const uint32_t key = va.key[v];
+    ijk[2] = key / dxy;
+    const int rem = key - ijk[2] * dxy;
+    ijk[1] = rem / dx;
+    ijk[0] = rem - ijk[1] * dx;
+  }
+  // wave aggregation: on surfaces nearly every lane of a wave belongs to the same (ground) cluster,
+  // so the wave's leading cluster is reduced with shuffles and committed by one lane.
+  const unsigned long long m_active = __ballot(active);
+  if (m_active == 0)
+    return;
+  const int lead_lane = __ffsll(static_cast<long long>(m_active)) - 1;
+  const uint32_t lead = __shfl(root, lead_lane);
+  const bool same = active && root == lead;
+  const uint32_t n_same = __popcll(__ballot(same));
+  int mn[3], mx[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+  {
+    mn[c] = same ? ijk[c] : 0x7fffffff;
+    mx[c] = same ? ijk[c] : static_cast<int>(0x80000000u);
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      mn[c] = min(mn[c], __shfl_xor(mn[c], s));
+      mx[c] = max(mx[c], __shfl_xor(mx[c], s));
+    }
+  if (static_cast<int>(threadIdx.x & 63) == lead_lane)
+  {
+    atomicAdd(&va.csize[lead], n_same);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      atomicMin(&va.cbox[6 * lead + c], mn[c]);
+      atomicMax(&va.cbox[6 * lead + 3 + c], mx[c]);
+    }
+  }
+  if (active && !same)
+  {
+    atomicAdd(&va.csize[root], 1u);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      atomicMin(&va.cbox[6 * root + c], ijk[c]);
+      atomicMax(&va.cbox[6 * root + 3 + c], ijk[c]);
+    }
+  }
+}
+
+// K8 + occupancy image of the voxel map: bit i = (map[i] > threshold), plus nVoxelsOver
+// (voxel_map.cpp:216-222, called per scan at vofod_nodelet.cpp:715).  Streaming, HBM-bound:
+// 4 B read per voxel, 1 bit written.  Each wave turns 64 consecutive voxels into one bitmap word
+// with a ballot; eight independent coalesced loads are kept in flight per lane.
+constexpr int MB_UNROLL = 8;
+__global__ __launch_bounds__(256) void k_mapbits(const float* __restrict__ map, uint64_t n, float threshold, unsigned long long* __restrict__ bits,
+                                                 unsigned long long* __restrict__ count)
+{
+  const uint64_t n_words = (n + 63) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  unsigned long long local = 0;
+  for (uint64_t w = wave * MB_UNROLL; w < n_words; w += n_waves * MB_UNROLL)
+  {
+    float m[MB_UNROLL];
+#pragma unroll
+    for (int u = 0; u < MB_UNROLL; u++)
+    {
+      const uint64_t idx = (w + u) * 64 + lane;
+      m[u] = idx < n ? map[idx] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < MB_UNROLL; u++)
+    {
+      const unsigned long long b = __ballot(m[u] > threshold);
+      if (w + u < n_words)
+      {
+        if (lane == 0)
+          bits[w + u] = b;
+        local += __popcll(b);
+      }
+    }
+  }
+  if (lane == 0 && local)
+    atomicAdd(count, local);
+}
+
+// K9: hasCloseTo (voxel_map.cpp:376-400) for every voxel against the occupancy image.
+// A cluster is close iff any member is (vofod_nodelet.cpp:727-748).
+__global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows,
+                                                  const FrameHdr* hdrs, const unsigned long long* __restrict__ mapbits, VoxelArrays va_all,
+                                                  const uint32_t* labels_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= h.V)
+    return;
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const uint32_t root = labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v];
+  if (va.cclose[root])
+    return;  // another member already decided (possibly stale read: only costs time)
+  const float4 p = va.pts[v];
+  // coordToIdx voxel_map.cpp:592-599
+  const int ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
+  const int oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
+  const int oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
+  for (int r = 0; r < cp.n_rows; r++)
+  {
+    const CloseRow row = rows[r];
+    const int y = oy + row.dy, z = oz + row.dz;
+    if (y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
+      continue;
+    const int lo = max(ox + row.x_lo, 0), hi = min(ox + row.x_hi, mg.sx - 1);
+    if (lo > hi)
+      continue;
+    const uint64_t L = (static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + lo;
+    const int nbits = hi - lo + 1;
+    const uint64_t wi = L >> 6;
+    const int sh = L & 63;
+    unsigned long long win = mapbits[wi] >> sh;
+    if (sh + nbits > 64)
+      win |= mapbits[wi + 1] << (64 - sh);
+    win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+    if (win)
+    {
+      va.cclose[root] = 1u;
+      return;
+    }
+  }
+}
+
+// K10 + cluster table + candidate members.
+//   - updateVoxel (vofod_nodelet.cpp:777-797) with score/flag chosen by the cluster's close flag (:946-948)
+//   - every root appends its cluster record (unordered; the host puts the table in canonical order)
+//   - voxels of far clusters that can still pass the min_points/max_size gates (:1679-1690) are
+//     appended to the candidate member list the host-side classification consumes.
+__global__ __launch_bounds__(256) void k_finalize(const GridParams g, const MapGeom mg, const UpdateParams up, FrameHdr* hdrs, VoxelArrays va_all,
+                                                  const uint32_t* labels_all, float* __restrict__ vmap, float* __restrict__ vflags, ClusterRec* table_all,
+                                                  CandMember* cand_all)
+{
+  FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= h.V)
+    return;
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const uint32_t root = labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v];
+  const uint32_t close = va.cclose[root];
+  const uint32_t size = va.csize[root];
+  const float4 p = va.pts[v];
+  if (!up.no_update)
+  {
+    const int ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
+    const int oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
+    const int oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
+    if (ox < 0 || ox >= mg.sx || oy < 0 || oy >= mg.sy || oz < 0 || oz >= mg.sz)
+      h.status = VOFOD_ERR_MAP_RANGE;
+    else
+    {
+      const uint64_t li = (static_cast<uint64_t>(oz) * mg.sy + oy) * mg.sx + ox;
+      const uint32_t c = min(__float_as_uint(p.w), 63u);
+      const float w = __uint_as_float((127u - c) << 23);  // 1.0f / float(1lu << c), exact
+      const float score = close ? up.score_point : up.score_unknown;
+      const float m = vmap[li];
+      vmap[li] = __fadd_rn(__fmul_rn(w, m), __fmul_rn(__fsub_rn(1.0f, w), score));
+      vflags[li] = close ? 2.0f : 3.0f;  // m_vflags_point / m_vflags_unknown (:2336-2337)
+    }
+  }
+  int ext_ok = 1;
+  const int32_t* box = &va.cbox[6 * root];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    ext_ok &= (static_cast<float>(box[3 + c] - box[c]) * g.leaf[c] <= up.cand_max_extent);
+  const bool cand = !close && static_cast<int>(size) >= up.min_points && ext_ok;
+  if (root == v)
+  {
+    const uint32_t slot = atomicAdd(&h.C, 1u);
+    ClusterRec rec;
+    rec.root = root;
+    rec.size = size;
+    for (int c = 0; c < 3; c++)
+    {
+      rec.imin[c] = box[c];
+      rec.imax[c] = box[3 + c];
+    }
+    rec.close = close;
+    rec.cand = cand ? 1u : 0u;
+    table_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + slot] = rec;
+  }
+  if (cand)
+  {
+    const uint32_t s = atomicAdd(&h.n_cand, 1u);
+    CandMember cm;
+    cm.root = root;
+    cm.v = v;
+    cand_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + s] = cm;
+  }
+}
+
+// small helpers used by the host-side classification tail -----------------------------------------
+
+// copy a clamped sub-box of a map into a dense staging buffer (x fastest)
+__global__ void k_read_box(const float* __restrict__ map, const MapGeom mg, int x0, int y0, int z0, int nx, int ny, int nz, float* __restrict__ dst)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = static_cast<uint32_t>(nx) * ny * nz;
+  if (t >= n)
+    return;
+  const int x = t % nx, y = (t / nx) % ny, z = t / (nx * ny);
+  dst[t] = map[(static_cast<uint64_t>(z0 + z) * mg.sy + (y0 + y)) * mg.sx + (x0 + x)];
+}
+
+__global__ void k_scatter_set(float* __restrict__ map, const uint64_t* __restrict__ idx, uint32_t n, float value)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n)
+    map[idx[t]] = value;
+}
+
+__global__ void k_fill(float* __restrict__ p, uint64_t n, float v)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    p[i] = v;
+}
+
+// initialize_apriori_map vofod_nodelet.cpp:339-341
+__global__ void k_apriori(float* __restrict__ map, const MapGeom mg, const float* __restrict__ xyz, uint32_t n)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n)
+    return;
+  const int ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(xyz[3 * t + 0], mg.off[0]), mg.vs_inv)));
+  const int oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(xyz[3 * t + 1], mg.off[1]), mg.vs_inv)));
+  const int oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(xyz[3 * t + 2], mg.off[2]), mg.vs_inv)));
+  if (ox < 0 || ox >= mg.sx || oy < 0 || oy >= mg.sy || oz < 0 || oz >= mg.sz)
+    return;
+  map[(static_cast<uint64_t>(oz) * mg.sy + oy) * mg.sx + ox] = INFINITY;
+}
+
+}  // namespace vk

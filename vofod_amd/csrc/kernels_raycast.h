@@ -1,0 +1,427 @@
+// Ray-cast map update (K14, K15) and separated-background-cluster removal (K16, K17, K6') kernels.
+//
+// raycast_cloud (vofod_nodelet.cpp:1397-1605): one lane per LiDAR ray walks the voxel map with the
+// Amanatides-Woo DDA of VoxelMap::forEachRay (voxel_map.cpp:229-263) and adds the in-voxel path length
+// to the raycast map with hardware float atomics; a single fused streaming pass then applies the
+// exponential pull of un-flagged traversed voxels towards scores/ray and clears flags + raycast map.
+//
+// updateSeparatedBGClusters (vofod_nodelet.cpp:1126-1277): thresholded voxels are enumerated in the
+// reference's x-outer/z-inner order through a transposed occupancy bitmap, voxelised with the counted
+// grid (positional count quirk), clustered, and unsure clusters are erased with an
+// order-independent atomic compare-and-swap application of m <- w1*m + w2*ray per (voxel, offset) pair.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_voxelize.h"
+
+namespace vr
+{
+using namespace vk;
+
+struct RayParams
+{
+  float R[9];
+  float origin[3];
+  float max_dist, min_intensity, voxel_size;
+  uint32_t n;
+};
+
+__device__ __forceinline__ int c2i(float x, float off, float inv) { return static_cast<int>(floorf(__fmul_rn(__fsub_rn(x, off), inv))); }
+
+__global__ __launch_bounds__(256) void k_raycast(const RayParams rp, const MapGeom mg, const char* __restrict__ intensity, const char* __restrict__ range, uint64_t stride,
+                                                 const float* __restrict__ lut_dirs, const float* __restrict__ lut_offs, const uint8_t* __restrict__ mask,
+                                                 float* __restrict__ ray, uint32_t* __restrict__ any_hit)
+{
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rp.n)
+    return;
+  const float inten = *reinterpret_cast<const float*>(intensity + static_cast<uint64_t>(idx) * stride);
+  const uint32_t rng = *reinterpret_cast<const uint32_t*>(range + static_cast<uint64_t>(idx) * stride);
+  if (inten < rp.min_intensity || (!mask[idx] && rng == 0))  // vofod_nodelet.cpp:1449
+    return;
+  float dir[3], start[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+  {
+    const float* R = &rp.R[3 * r];
+    dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(R[0], lut_dirs[3 * idx]), __fmul_rn(R[1], lut_dirs[3 * idx + 1])), __fmul_rn(R[2], lut_dirs[3 * idx + 2]));
+    start[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(R[0], lut_offs[3 * idx]), __fmul_rn(R[1], lut_offs[3 * idx + 1])), __fmul_rn(R[2], lut_offs[3 * idx + 2])), rp.origin[r]);
+  }
+  const float ray_dist = __fmul_rn(0.001f, static_cast<float>(rng));                                  // :1455-1456
+  const float length = ray_dist == 0.0f ? rp.max_dist : fminf(__fsub_rn(ray_dist, rp.voxel_size), rp.max_dist);  // :1457
+  int cur[3] = {c2i(start[0], mg.off[0], mg.vs_inv), c2i(start[1], mg.off[1], mg.vs_inv), c2i(start[2], mg.off[2], mg.vs_inv)};
+  const int lim[3] = {mg.sx, mg.sy, mg.sz};
+  if (cur[0] < 0 || cur[0] >= lim[0] || cur[1] < 0 || cur[1] >= lim[1] || cur[2] < 0 || cur[2] >= lim[2])  // :1482
+    return;
+  // forEachRay voxel_map.cpp:229-263
+  const float half = mg.vs / 2.0f;
+  float tdelta[3], tmax[3];
+  int step[3], last[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+  {
+    const float absdir = fabsf(dir[a]);
+    step[a] = (dir[a] > 0.0f) - (dir[a] < 0.0f);
+    tdelta[a] = __fmul_rn(__fdiv_rn(1.0f, absdir), mg.vs);
+    const float ctr = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cur[a]), 0.5f), mg.vs), mg.off[a]);
+    const float ctr_offset = __fsub_rn(ctr, start[a]);
+    tmax[a] = __fdiv_rn(__fadd_rn(half, __fmul_rn(static_cast<float>(step[a]), ctr_offset)), absdir);
+    last[a] = step[a] > 0 ? lim[a] - 1 : 0;
+  }
+  float prev = 0.0f;
+  bool any = false;
+  while (prev < length)
+  {
+    int i = 0;
+    if (tmax[1] < tmax[i])
+      i = 1;
+    if (tmax[2] < tmax[i])
+      i = 2;
+    const float dist = i == 0 ? tmax[0] : (i == 1 ? tmax[1] : tmax[2]);
+    const float dd = __fsub_rn(fminf(dist, length), prev);
+    if (dd != 0.0f)
+    {
+      unsafeAtomicAdd(&ray[(static_cast<uint64_t>(cur[2]) * mg.sy + cur[1]) * mg.sx + cur[0]], dd);
+      any = true;
+    }
+    prev = dist;
+    const int ci = i == 0 ? cur[0] : (i == 1 ? cur[1] : cur[2]);
+    const int li = i == 0 ? last[0] : (i == 1 ? last[1] : last[2]);
+    if (ci == li)
+      break;
+    if (i == 0)
+    {
+      cur[0] += step[0];
+      tmax[0] = __fadd_rn(tmax[0], tdelta[0]);
+    }
+    else if (i == 1)
+    {
+      cur[1] += step[1];
+      tmax[1] = __fadd_rn(tmax[1], tdelta[1]);
+    }
+    else
+    {
+      cur[2] += step[2];
+      tmax[2] = __fadd_rn(tmax[2], tdelta[2]);
+    }
+  }
+  if (any)
+    *any_hit = 1u;
+}
+
+// max of a non-negative float array (order-preserving on the raw bits), for the old update rule (:1542)
+__global__ __launch_bounds__(256) void k_max_nonneg(const float* __restrict__ v, uint64_t n, uint32_t* out)
+{
+  uint32_t m = 0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    const float x = v[i];
+    if (x > 0.0f)
+      m = max(m, __float_as_uint(x));
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1)
+    m = max(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0 && m)
+    atomicMax(out, m);
+}
+
+struct SweepParams
+{
+  float its_diff;
+  float ray_score;
+  float weighting_factor;  // new rule: coef / (sqrt(3)*vs)          (:1555-1556)
+  float weight;            // old rule: coef                          (:1578)
+  float max_val;           // old rule normaliser                      (:1542)
+  int32_t new_rule;
+};
+
+// K15: fused update sweep (:1557-1602).  Reads flags + raycast (+ map where a ray passed), writes map,
+// clears flags and the raycast accumulator.  Stores are issued only where a value actually changes.
+__global__ __launch_bounds__(256) void k_ray_sweep(const SweepParams sp, uint64_t n, float* __restrict__ map, float* __restrict__ flags, float* __restrict__ ray)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    const float flag = flags[i];
+    const float r = ray[i];
+    if (flag == 0.0f && r > 0.0f)
+    {
+      float w1;
+      if (sp.new_rule)
+      {
+        const float n_int = __fmul_rn(sp.weighting_factor, r);
+        w1 = static_cast<float>(exp2(static_cast<double>(__fmul_rn(-sp.its_diff, n_int))));  // std::pow(2, x) evaluates in double
+      }
+      else
+      {
+        const float norm_val = __fdiv_rn(r, sp.max_val);
+        const float w_single = __fmul_rn(sp.weight, __fsqrt_rn(norm_val));
+        w1 = fminf(fmaxf(powf(__fsub_rn(1.0f, w_single), sp.its_diff), 0.0f), 1.0f);
+      }
+      const float w2 = __fsub_rn(1.0f, w1);
+      map[i] = __fadd_rn(__fmul_rn(w1, map[i]), __fmul_rn(w2, sp.ray_score));
+    }
+    if (flag != 0.0f)
+      flags[i] = 0.0f;
+    if (r != 0.0f)
+      ray[i] = 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------ generic exclusive scan (u32)
+constexpr int GS_EPT = 8;
+constexpr int GS_EPB = 256 * GS_EPT;
+
+__global__ __launch_bounds__(256) void k_gscan_a(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ bsum)
+{
+  const uint32_t base = blockIdx.x * GS_EPB + threadIdx.x * GS_EPT;
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < GS_EPT; k++)
+    if (base + k < n)
+      c += in[base + k];
+  __shared__ uint32_t lds4[4];
+  uint32_t total;
+  block_excl_scan_256(c, lds4, &total);
+  if (threadIdx.x == 0)
+    bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_gscan_b(uint32_t* bsum, uint32_t nblk, uint32_t* total_out)
+{
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0)
+    carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblk; base += 1024)
+  {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblk ? bsum[i] : 0;
+    const uint32_t incl = wave_incl_scan(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63)
+      wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = carry_s;
+    for (int w = 0; w < wave; w++)
+      off += wsum[w];
+    if (i < nblk)
+      bsum[i] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry_s = off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out)
+    *total_out = carry_s;
+}
+
+// out has n+1 entries: out[i] = sum(in[0..i)), out[n] = total
+__global__ __launch_bounds__(256) void k_gscan_c(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ out)
+{
+  const uint32_t base = blockIdx.x * GS_EPB + threadIdx.x * GS_EPT;
+  uint32_t vals[GS_EPT];
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < GS_EPT; k++)
+  {
+    vals[k] = (base + k < n) ? in[base + k] : 0u;
+    c += vals[k];
+  }
+  __shared__ uint32_t lds4[4];
+  uint32_t total;
+  uint32_t run = block_excl_scan_256(c, lds4, &total) + bsum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < GS_EPT; k++)
+  {
+    if (base + k < n)
+      out[base + k] = run;
+    run += vals[k];
+    if (base + k + 1 == n)
+      out[n] = run;
+  }
+}
+
+// ------------------------------------------------------------------ sepclusters
+
+// K16a: transposed occupancy image.  Bit t = z + y*sz + x*sz*sy of `tbits` is set iff map(x,y,z) > thr,
+// read from the x-fastest occupancy image (small, cache resident) so the float map is not re-streamed.
+__global__ __launch_bounds__(256) void k_transpose_bits(const MapGeom mg, const unsigned long long* __restrict__ mapbits, unsigned long long* __restrict__ tbits)
+{
+  const uint64_t n_words = (mg.n + 63) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint64_t szy = static_cast<uint64_t>(mg.sz) * mg.sy;
+  for (uint64_t w = wave; w < n_words; w += n_waves)
+  {
+    const uint64_t t = w * 64 + lane;
+    bool set = false;
+    if (t < mg.n)
+    {
+      const uint64_t x = t / szy;
+      const uint64_t rem = t - x * szy;
+      const uint64_t y = rem / mg.sz;
+      const uint64_t z = rem - y * mg.sz;
+      const uint64_t li = (z * mg.sy + y) * mg.sx + x;
+      set = (mapbits[li >> 6] >> (li & 63)) & 1ull;
+    }
+    const unsigned long long b = __ballot(set);
+    if (lane == 0)
+      tbits[w] = b;
+  }
+}
+
+// word popcounts of a plain bitmap -> u32 array (input of the generic scan)
+__global__ __launch_bounds__(256) void k_popc_words(const unsigned long long* __restrict__ bits, uint32_t n_words, uint32_t* __restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words)
+    out[i] = __popcll(bits[i]);
+}
+
+// K16b: voxelsAsVoxelPC (voxel_map.cpp:187-212): emit (x,y,z as floats, map value) in transposed-bit order
+// plus the "sure" flag (value > sure threshold) that the counted grid's positional count consumes.
+__global__ __launch_bounds__(256) void k_emit_vpc(const MapGeom mg, const float* __restrict__ map, const unsigned long long* __restrict__ tbits,
+                                                  const uint32_t* __restrict__ tprefix, uint32_t n_words, float thr_sure, float* __restrict__ px,
+                                                  float* __restrict__ py, float* __restrict__ pz, float* __restrict__ pi, uint32_t* __restrict__ sure)
+{
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words)
+    return;
+  unsigned long long bits = tbits[w];
+  uint32_t rank = tprefix[w];
+  const uint64_t szy = static_cast<uint64_t>(mg.sz) * mg.sy;
+  while (bits)
+  {
+    const int b = __ffsll(static_cast<long long>(bits)) - 1;
+    bits &= bits - 1;
+    const uint64_t t = static_cast<uint64_t>(w) * 64 + b;
+    const uint64_t x = t / szy;
+    const uint64_t rem = t - x * szy;
+    const uint64_t y = rem / mg.sz;
+    const uint64_t z = rem - y * mg.sz;
+    const float m = map[(z * mg.sy + y) * mg.sx + x];
+    px[rank] = static_cast<float>(x);
+    py[rank] = static_cast<float>(y);
+    pz[rank] = static_cast<float>(z);
+    pi[rank] = m;
+    sure[rank] = m > thr_sure ? 1u : 0u;
+    rank++;
+  }
+}
+
+// per-voxel point counts of the weighted emission -> u32 array
+__global__ __launch_bounds__(256) void k_voxel_counts(const FrameHdr* hdr, const float4* __restrict__ pts, uint32_t* __restrict__ out)
+{
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < hdr->V)
+    out[v] = __float_as_uint(pts[v].w);
+}
+
+// K6': voxel_grid_counted.cpp:185-191: range_k = #{input positions p in [first_k, last_k): intensity_p > thr}
+// with [first_k,last_k) the run of voxel k in the sorted index vector = exclusive prefix of the voxel sizes.
+__global__ __launch_bounds__(256) void k_counted_range(const FrameHdr* hdr, const uint32_t* __restrict__ first, const uint32_t* __restrict__ sure_prefix, uint32_t n_points,
+                                                       float4* __restrict__ pts)
+{
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= hdr->V)
+    return;
+  const uint32_t a = min(first[v], n_points), b = min(first[v + 1], n_points);
+  pts[v].w = __uint_as_float(sure_prefix[b] - sure_prefix[a]);
+}
+
+// intensity > threshold flags of an arbitrary strided column (stateless counted grid)
+__global__ __launch_bounds__(256) void k_flag_over(const char* __restrict__ col, uint64_t stride, uint32_t n, float thr, uint32_t* __restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = *reinterpret_cast<const float*>(col + static_cast<uint64_t>(i) * stride) > thr ? 1u : 0u;
+}
+
+// sum of `range` per cluster (vofod_nodelet.cpp:1175-1183) + "any cluster sure" flag
+__global__ __launch_bounds__(256) void k_cluster_sure(const FrameHdr* hdr, const float4* __restrict__ pts, const uint32_t* __restrict__ labels, uint32_t* __restrict__ n_sure)
+{
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= hdr->V)
+    return;
+  const uint32_t r = __float_as_uint(pts[v].w);
+  if (r)
+    atomicAdd(&n_sure[labels[v]], r);
+}
+
+__global__ __launch_bounds__(256) void k_any_sure(const FrameHdr* hdr, const uint32_t* __restrict__ labels, const uint32_t* __restrict__ n_sure, uint32_t min_sure, uint32_t* out)
+{
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= hdr->V)
+    return;
+  if (labels[v] == v && n_sure[v] >= min_sure)
+    out[0] = 1u;
+  if (labels[v] == v)
+    atomicMax(&out[1], n_sure[v]);
+}
+
+struct EraseParams
+{
+  float w1, w2, update_val;
+  uint32_t min_sure;
+  int32_t n_offsets;
+};
+
+// K17: erase stencil (vofod_nodelet.cpp:1244-1272).  Every (voxel of an unsure cluster, offset) pair applies
+// m <- w1*m + w2*ray once; all applications are the same function, so applying them with an atomic
+// compare-and-swap in any order reproduces the reference's sequential result bit for bit.
+__global__ __launch_bounds__(256) void k_sep_erase(const EraseParams ep, const MapGeom mg, const FrameHdr* hdr, const float4* __restrict__ pts,
+                                                   const uint32_t* __restrict__ labels, const uint32_t* __restrict__ n_sure, const int* __restrict__ offsets,
+                                                   float* __restrict__ map)
+{
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= hdr->V)
+    return;
+  if (n_sure[labels[v]] >= ep.min_sure)
+    return;
+  const float4 p = pts[v];
+  const int pos[3] = {static_cast<int>(p.x), static_cast<int>(p.y), static_cast<int>(p.z)};  // cast<int>() truncates (:1252)
+  for (int o = 0; o < ep.n_offsets; o++)
+  {
+    const int x = pos[0] + offsets[3 * o], y = pos[1] + offsets[3 * o + 1], z = pos[2] + offsets[3 * o + 2];
+    if (x < 0 || x >= mg.sx || y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
+      continue;
+    uint32_t* a = reinterpret_cast<uint32_t*>(&map[(static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + x]);
+    uint32_t old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true)
+    {
+      const float m = __uint_as_float(old);
+      const float nm = __fadd_rn(__fmul_rn(ep.w1, m), __fmul_rn(ep.w2, ep.update_val));
+      const uint32_t prev = atomicCAS(a, old, __float_as_uint(nm));
+      if (prev == old)
+        break;
+      old = prev;
+    }
+  }
+}
+
+// device buffers owned by the sepclusters stage
+struct SepState
+{
+  unsigned long long* d_tbits = nullptr;
+  uint32_t* d_tpop = nullptr;     // word popcounts, then reused
+  uint32_t* d_tprefix = nullptr;  // n_words + 1
+  uint32_t* d_bsum = nullptr;
+  size_t words_cap = 0;
+  float *d_px = nullptr, *d_py = nullptr, *d_pz = nullptr, *d_pi = nullptr;
+  uint32_t* d_sure = nullptr;      // flags per input position
+  uint32_t* d_sure_pre = nullptr;  // P + 1
+  uint32_t* d_vcnt = nullptr;      // per ds voxel
+  uint32_t* d_first = nullptr;     // V' + 1
+  uint32_t* d_nsure = nullptr;     // per root
+  size_t pts_cap = 0;
+  int* d_offsets = nullptr;
+  uint32_t* d_small = nullptr;  // [0] P total, [1] any sure, [2] max sure, [3] V total
+  uint32_t* h_small = nullptr;  // pinned
+  uint32_t P = 0;
+  GridParams g{};
+};
+
+}  // namespace vr

@@ -1,0 +1,426 @@
+// Voxelisation kernels (K1-K6 of SURVEY.md §2.1) for gfx950.
+//
+// Replaces VoxelGridWeighted/VoxelGridCounted::filterImpl (voxel_grid_weighted.cpp:41-190,
+// voxel_grid_counted.cpp:49-196) together with the two pcl::CropBox passes and
+// pcl::transformPointCloud of filterAndTransform (vofod_nodelet.cpp:621-684).
+//
+// Design: instead of the reference's sort of (key, point) pairs, occupied cells are marked in a
+// per-frame *occupancy bitmap* whose bit order is the reference's key order (x fastest).  A
+// prefix sum of the bitmap's word popcounts gives every occupied cell its rank = its position in
+// the reference's sorted output, so a plain sweep of the bitmap emits the weighted cloud in the
+// reference's order, the per-voxel point counts are integer atomics on rank slots, and the same
+// bitmap + prefix array later serve as the O(1) neighbour lookup of the clustering kernel.
+// All index arithmetic reproduces the reference's float expressions exactly (no FMA contraction).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace vk
+{
+
+__device__ __forceinline__ int f2ord(float f)
+{
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__device__ __forceinline__ float ldf(const char* base, uint64_t stride, uint32_t i) { return *reinterpret_cast<const float*>(base + static_cast<uint64_t>(i) * stride); }
+
+// CropBox (negative, sensor frame) -> transformPointCloud -> CropBox (positive, world frame):
+// vofod_nodelet.cpp:625-655.  Inclusive boxes; non-finite points are dropped.
+__device__ __forceinline__ bool fetch_point(const FrameArgs& a, const GridParams& g, uint32_t i, float q[3])
+{
+  const float px = ldf(a.x, a.stride, i), py = ldf(a.y, a.stride, i), pz = ldf(a.z, a.stride, i);
+  if (!(a.flags & FA_SCAN))
+  {
+    q[0] = px;
+    q[1] = py;
+    q[2] = pz;
+    return true;
+  }
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz)))
+    return false;
+  const bool in_ex = !(px < g.ex_min[0] || py < g.ex_min[1] || pz < g.ex_min[2] || px > g.ex_max[0] || py > g.ex_max[1] || pz > g.ex_max[2]);
+  if (in_ex)
+    return false;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+  {
+    // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
+    const float p0 = __fmul_rn(a.tf[4 * r + 0], px);
+    const float p1 = __fmul_rn(a.tf[4 * r + 1], py);
+    const float p2 = __fmul_rn(a.tf[4 * r + 2], pz);
+    q[r] = __fadd_rn(p0, __fadd_rn(p1, __fadd_rn(p2, a.tf[4 * r + 3])));
+  }
+  const bool in_op = !(q[0] < g.op_min[0] || q[1] < g.op_min[1] || q[2] < g.op_min[2] || q[0] > g.op_max[0] || q[1] > g.op_max[1] || q[2] > g.op_max[2]);
+  return in_op;
+}
+
+// voxel_grid_weighted.cpp:131-136
+__device__ __forceinline__ uint32_t cell_key(const FrameHdr& h, const GridParams& g, const float q[3])
+{
+  const int i0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], h.offset[0]), g.inv[0])));
+  const int i1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], h.offset[1]), g.inv[1])));
+  const int i2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], h.offset[2]), g.inv[2])));
+  return static_cast<uint32_t>(i0 + i1 * h.div_b[0] + i2 * h.div_b[0] * h.div_b[1]);
+}
+
+__global__ void k_init_hdr(FrameHdr* hdrs)
+{
+  FrameHdr& h = hdrs[blockIdx.x];
+  if (threadIdx.x == 0)
+  {
+    for (int a = 0; a < 3; a++)
+    {
+      h.bb_min[a] = 0x7fffffff;
+      h.bb_max[a] = static_cast<int>(0x80000000u);
+    }
+    h.n_in = 0;
+    h.status = VOFOD_OK;
+    h.n_cells = h.n_words = 0;
+    h.V = h.C = h.n_cand = 0;
+    h.need_words = 0;
+  }
+}
+
+// K1-K4a: crop + transform + crop fused with pcl::getMinMax3D (voxel_grid_weighted.cpp:58).
+__global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridParams g, FrameHdr* hdrs)
+{
+  const FrameArgs& a = args[blockIdx.y];
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
+  uint32_t cnt = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+  {
+    float q[3];
+    if (!fetch_point(a, g, i, q))
+      continue;
+    cnt++;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      const int o = f2ord(q[c]);
+      mn[c] = min(mn[c], o);
+      mx[c] = max(mx[c], o);
+    }
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1)
+  {
+    cnt += __shfl_xor(cnt, s);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      mn[c] = min(mn[c], __shfl_xor(mn[c], s));
+      mx[c] = max(mx[c], __shfl_xor(mx[c], s));
+    }
+  }
+  if ((threadIdx.x & 63) == 0 && cnt)
+  {
+    FrameHdr& h = hdrs[blockIdx.y];
+    atomicAdd(&h.n_in, cnt);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      atomicMin(&h.bb_min[c], mn[c]);
+      atomicMax(&h.bb_max[c], mx[c]);
+    }
+  }
+}
+
+// voxel_grid_weighted.cpp:61-113: overflow guard, min_b/max_b, offset (+ alignment), div_b.
+__global__ void k_grid(const GridParams g, FrameHdr* hdrs)
+{
+  if (threadIdx.x != 0)
+    return;
+  FrameHdr& h = hdrs[blockIdx.x];
+  if (h.n_in == 0)
+    return;
+  float min_p[3], max_p[3];
+  for (int c = 0; c < 3; c++)
+  {
+    min_p[c] = ord2f(h.bb_min[c]);
+    max_p[c] = ord2f(h.bb_max[c]);
+  }
+  const int64_t dx = static_cast<int64_t>(__fmul_rn(__fsub_rn(max_p[0], min_p[0]), g.inv[0])) + 2;
+  const int64_t dy = static_cast<int64_t>(__fmul_rn(__fsub_rn(max_p[1], min_p[1]), g.inv[1])) + 2;
+  const int64_t dz = static_cast<int64_t>(__fmul_rn(__fsub_rn(max_p[2], min_p[2]), g.inv[2])) + 2;
+  // each factor is < 2^40 for finite floats only when the spans are sane; test stepwise to stay in int64
+  const int64_t lim = 0x7fffffffll;
+  if (dx > lim || dy > lim || dz > lim || dx * dy > lim || dx * dy * dz > lim)
+  {
+    h.status = VOFOD_ERR_INDEX_OVERFLOW;
+    h.n_in = 0;
+    return;
+  }
+  int64_t cells = 1;
+  for (int c = 0; c < 3; c++)
+  {
+    int min_b = static_cast<int>(floorf(__fmul_rn(min_p[c], g.inv[c])));
+    const int max_b = static_cast<int>(floorf(__fmul_rn(max_p[c], g.inv[c])));
+    float offset = __fmul_rn(static_cast<float>(min_b), g.leaf[c]);
+    if (g.align)
+    {
+      offset = __fsub_rn(offset, g.aco[c]);
+      min_b = static_cast<int>(floorf(__fmul_rn(offset, g.inv[c])));
+    }
+    h.offset[c] = offset;
+    h.min_b[c] = min_b;
+    h.div_b[c] = max_b - min_b + 1;
+    cells *= h.div_b[c];
+  }
+  if (cells > lim)
+  {
+    h.status = VOFOD_ERR_INDEX_OVERFLOW;
+    h.n_in = 0;
+    return;
+  }
+  h.n_cells = static_cast<uint32_t>(cells);
+  h.n_words = static_cast<uint32_t>((cells + 63) >> 6);
+  h.need_words = h.n_words;
+  if (h.n_words > g.words_cap)
+  {
+    h.status = VOFOD_ERR_CAPACITY;
+    h.n_in = 0;
+    h.n_cells = h.n_words = 0;
+  }
+}
+
+// K4b: mark occupied cells.  One 64-bit atomic OR per point, skipped when the bit is already set.
+__global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, unsigned long long* bitmaps)
+{
+  const FrameArgs& a = args[blockIdx.y];
+  const FrameHdr& h = hdrs[blockIdx.y];
+  if (h.n_in == 0)
+    return;
+  unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+  {
+    float q[3];
+    if (!fetch_point(a, g, i, q))
+      continue;
+    const uint32_t key = cell_key(h, g, q);
+    if (key >= h.n_cells)
+      continue;  // rounding artefact outside the lattice (the reference would alias it onto another cell)
+    const unsigned long long bit = 1ull << (key & 63);
+    if (!(bm[key >> 6] & bit))
+      atomicOr(&bm[key >> 6], bit);
+  }
+}
+
+// ---- exclusive prefix sum of the bitmap's word popcounts (3 phases) ------------------------
+constexpr int SCAN_WPT = 4;                    // words per thread
+constexpr int SCAN_WPB = 256 * SCAN_WPT;       // words per block
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1)
+  {
+    const uint32_t t = __shfl_up(v, s);
+    if (lane >= s)
+      v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the block total via *total
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds4, uint32_t* total)
+{
+  const uint32_t incl = wave_incl_scan(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 63)
+    lds4[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++)
+    base += lds4[w];
+  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_a(const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps, uint32_t* blocksums, uint32_t nblk_cap)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t w0 = blockIdx.x * SCAN_WPB + threadIdx.x * SCAN_WPT;
+  if (blockIdx.x * SCAN_WPB >= h.n_words)
+    return;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_WPT; k++)
+    if (w0 + k < h.n_words)
+      c += __popcll(bm[w0 + k]);
+  __shared__ uint32_t lds4[4];
+  uint32_t total;
+  block_excl_scan_256(c, lds4, &total);
+  if (threadIdx.x == 0)
+    blocksums[static_cast<size_t>(blockIdx.y) * nblk_cap + blockIdx.x] = total;
+}
+
+// one 1024-thread block per frame: exclusive scan of the block sums, total -> hdr.V
+__global__ __launch_bounds__(1024) void k_scan_b(const GridParams g, FrameHdr* hdrs, uint32_t* blocksums, uint32_t nblk_cap)
+{
+  FrameHdr& h = hdrs[blockIdx.x];
+  const uint32_t nblk = (h.n_words + SCAN_WPB - 1) / SCAN_WPB;
+  uint32_t* bs = blocksums + static_cast<size_t>(blockIdx.x) * nblk_cap;
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0)
+    carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblk; base += 1024)
+  {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblk ? bs[i] : 0;
+    const uint32_t incl = wave_incl_scan(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63)
+      wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = carry_s;
+    for (int w = 0; w < wave; w++)
+      off += wsum[w];
+    if (i < nblk)
+      bs[i] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry_s = off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    h.V = carry_s;
+    if (carry_s > g.vox_cap)
+    {
+      h.status = VOFOD_ERR_CAPACITY;
+      h.V = 0;
+    }
+  }
+}
+
+// Per-voxel device arrays of one frame (struct of arrays, V entries used).
+struct VoxelArrays
+{
+  float4* pts;         // x, y, z, bits(count)  == vofod_point_xyzr
+  uint32_t* key;       // lattice key (ascending)
+  uint32_t* parent;    // union-find forest, afterwards the label
+  uint32_t* csize;     // per root: cluster size
+  int32_t* cbox;       // per root: imin[3], imax[3]
+  uint32_t* cclose;    // per root: close flag
+};
+
+__device__ __forceinline__ VoxelArrays frame_voxels(const VoxelArrays& base, uint32_t frame, uint32_t vox_cap)
+{
+  VoxelArrays v;
+  const size_t o = static_cast<size_t>(frame) * vox_cap;
+  v.pts = base.pts + o;
+  v.key = base.key + o;
+  v.parent = base.parent + o;
+  v.csize = base.csize + o;
+  v.cbox = base.cbox + o * 6;
+  v.cclose = base.cclose + o;
+  return v;
+}
+
+// K6: phase c of the scan fused with the emission of the weighted cloud in key order
+// (voxel_grid_weighted.cpp:155-188): centre = (ijk + 0.5)*leaf + offset, weight filled by k_count.
+__global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
+                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  if (blockIdx.x * SCAN_WPB >= h.n_words || h.V == 0)
+    return;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const uint32_t w0 = blockIdx.x * SCAN_WPB + threadIdx.x * SCAN_WPT;
+  unsigned long long words[SCAN_WPT];
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_WPT; k++)
+  {
+    words[k] = (w0 + k < h.n_words) ? bm[w0 + k] : 0ull;
+    c += __popcll(words[k]);
+  }
+  __shared__ uint32_t lds4[4];
+  uint32_t total;
+  uint32_t rank = block_excl_scan_256(c, lds4, &total) + blocksums[static_cast<size_t>(blockIdx.y) * nblk_cap + blockIdx.x];
+  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+#pragma unroll
+  for (int k = 0; k < SCAN_WPT; k++)
+  {
+    if (w0 + k < h.n_words)
+      wprefix[w0 + k] = rank;
+    unsigned long long w = words[k];
+    while (w)
+    {
+      const int b = __ffsll(static_cast<long long>(w)) - 1;
+      w &= w - 1;
+      const uint32_t key = (w0 + k) * 64u + b;
+      const int k2 = key / dxy;
+      const int rem = key - k2 * dxy;
+      const int k1 = rem / dx;
+      const int k0 = rem - k1 * dx;
+      float4 p;
+      p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
+      p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
+      p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+      p.w = __uint_as_float(0u);
+      va.pts[rank] = p;
+      va.key[rank] = key;
+      va.parent[rank] = rank;
+      va.csize[rank] = 0;
+      va.cclose[rank] = 0;
+#pragma unroll
+      for (int c3 = 0; c3 < 3; c3++)
+      {
+        va.cbox[6 * rank + c3] = 0x7fffffff;
+        va.cbox[6 * rank + 3 + c3] = static_cast<int>(0x80000000u);
+      }
+      rank++;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t rank_of(const unsigned long long* bm, const uint32_t* wprefix, uint32_t key)
+{
+  const uint32_t w = key >> 6;
+  return wprefix[w] + __popcll(bm[w] & ((1ull << (key & 63)) - 1ull));
+}
+
+// K6 weights: number of input points per voxel (voxel_grid_weighted.cpp:181), integer atomics on rank slots.
+// `pt_rank` (nullable) records each input point's voxel rank (0xffffffff when dropped) for the counted grid.
+__global__ __launch_bounds__(256) void k_count(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps,
+                                               const uint32_t* wprefix_all, VoxelArrays va_all, uint32_t* pt_rank, uint32_t pt_cap)
+{
+  const FrameArgs& a = args[blockIdx.y];
+  const FrameHdr& h = hdrs[blockIdx.y];
+  if (h.n_in == 0 || h.V == 0)
+    return;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+  {
+    float q[3];
+    uint32_t r = 0xffffffffu;
+    if (fetch_point(a, g, i, q))
+    {
+      const uint32_t key = cell_key(h, g, q);
+      if (key < h.n_cells)
+      {
+        r = rank_of(bm, wprefix, key);
+        atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[r].w), 1u);
+      }
+    }
+    if (pt_rank)
+      pt_rank[static_cast<size_t>(blockIdx.y) * pt_cap + i] = r;
+  }
+}
+
+}  // namespace vk

@@ -1,0 +1,963 @@
+// libvofod_hip.so — the product: C++ host driver + hand-written gfx950 kernels behind include/vofod.h.
+// One handle owns one HIP stream, the three voxel maps in HBM and a per-frame workspace; a scan (or a
+// batch of independent scans, one grid.y slice each) is one stream-ordered chain of kernels followed by
+// a single read-back of the small cluster table, after which the host runs the sequential
+// classification tail (host_tail.h) on the few candidate clusters.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "host_tail.h"
+#include "kernels_cluster.h"
+#include "kernels_raycast.h"
+#include "kernels_voxelize.h"
+
+using namespace vk;
+
+namespace
+{
+
+constexpr uint32_t SPEC_C = 512;   // cluster records read back speculatively with the header
+constexpr uint32_t SPEC_M = 2048;  // candidate members read back speculatively
+
+struct CandMemberX
+{
+  uint32_t root, v;
+  float x, y, z;
+  uint32_t count;
+};
+
+struct PackedFrame
+{
+  FrameHdr hdr;
+  uint32_t pad[32 - sizeof(FrameHdr) / 4];
+  ClusterRec table[SPEC_C];
+  CandMemberX members[SPEC_M];
+};
+static_assert(sizeof(FrameHdr) <= 128, "FrameHdr grew past its slot");
+
+__global__ void k_pack(const GridParams g, const FrameHdr* hdrs, const ClusterRec* table_all, const CandMember* cand_all, VoxelArrays va_all, PackedFrame* out)
+{
+  const uint32_t f = blockIdx.y;
+  const FrameHdr h = hdrs[f];
+  PackedFrame& o = out[f];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0)
+    o.hdr = h;
+  if (t < min(h.C, SPEC_C))
+    o.table[t] = table_all[static_cast<size_t>(f) * g.vox_cap + t];
+  if (t < min(h.n_cand, SPEC_M))
+  {
+    const CandMember cm = cand_all[static_cast<size_t>(f) * g.vox_cap + t];
+    const float4 p = va_all.pts[static_cast<size_t>(f) * g.vox_cap + cm.v];
+    CandMemberX x;
+    x.root = cm.root;
+    x.v = cm.v;
+    x.x = p.x;
+    x.y = p.y;
+    x.z = p.z;
+    x.count = __float_as_uint(p.w);
+    o.members[t] = x;
+  }
+}
+
+__global__ void k_gather_members(const GridParams g, uint32_t frame, uint32_t n, const CandMember* cand_all, VoxelArrays va_all, CandMemberX* out)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n)
+    return;
+  const CandMember cm = cand_all[static_cast<size_t>(frame) * g.vox_cap + t];
+  const float4 p = va_all.pts[static_cast<size_t>(frame) * g.vox_cap + cm.v];
+  CandMemberX x;
+  x.root = cm.root;
+  x.v = cm.v;
+  x.x = p.x;
+  x.y = p.y;
+  x.z = p.z;
+  x.count = __float_as_uint(p.w);
+  out[t] = x;
+}
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(const clk::time_point& t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+inline float ulp32(float x)
+{
+  x = std::fabs(x);
+  return std::nextafterf(x, INFINITY) - x;
+}
+
+}  // namespace
+
+#define HIPCHK(expr)                                                                                         \
+  do                                                                                                         \
+  {                                                                                                          \
+    const hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                                    \
+    {                                                                                                        \
+      h->err = std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"; \
+      return VOFOD_ERR_DEVICE;                                                                               \
+    }                                                                                                        \
+  } while (0)
+
+struct Workspace
+{
+  uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0;
+  FrameArgs* d_args = nullptr;
+  FrameHdr* d_hdrs = nullptr;
+  unsigned long long* d_bitmaps = nullptr;
+  uint32_t* d_wprefix = nullptr;
+  uint32_t* d_blocksums = nullptr;
+  VoxelArrays va{};
+  uint32_t* d_labels = nullptr;
+  ClusterRec* d_table = nullptr;
+  CandMember* d_cand = nullptr;
+  uint32_t* d_ptrank = nullptr;
+  float* d_stage = nullptr;  // F * pt_cap * 5 words: x, y, z, intensity, range of host-resident inputs
+  PackedFrame* d_packed = nullptr;
+  PackedFrame* h_packed = nullptr;  // pinned
+  std::vector<FrameArgs> h_args;
+
+  void release()
+  {
+    void* ptrs[] = {d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
+    for (void* p : ptrs)
+      if (p)
+        (void)hipFree(p);
+    if (h_packed)
+      (void)hipHostFree(h_packed);
+    *this = Workspace();
+  }
+
+  hipError_t ensure(uint32_t F_, uint32_t pt_cap_, uint32_t vox_cap_, uint32_t words_cap_)
+  {
+    if (F_ <= F && pt_cap_ <= pt_cap && vox_cap_ <= vox_cap && words_cap_ <= words_cap)
+      return hipSuccess;
+    F_ = std::max(F_, F);
+    pt_cap_ = std::max(pt_cap_, pt_cap);
+    vox_cap_ = std::max(vox_cap_, vox_cap);
+    words_cap_ = std::max(words_cap_, words_cap);
+    release();
+    F = F_;
+    pt_cap = pt_cap_;
+    vox_cap = vox_cap_;
+    words_cap = words_cap_;
+    nblk_cap = (words_cap + SCAN_WPB - 1) / SCAN_WPB + 1;
+    hipError_t e;
+    const size_t FV = static_cast<size_t>(F) * vox_cap;
+#define WS_ALLOC(ptr, bytes)                                     \
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ptr), (bytes))) != hipSuccess) \
+    return e;
+    WS_ALLOC(d_args, sizeof(FrameArgs) * F);
+    WS_ALLOC(d_hdrs, sizeof(FrameHdr) * F);
+    WS_ALLOC(d_bitmaps, sizeof(unsigned long long) * F * (static_cast<size_t>(words_cap) + 2));
+    WS_ALLOC(d_wprefix, sizeof(uint32_t) * F * (static_cast<size_t>(words_cap) + 2));
+    WS_ALLOC(d_blocksums, sizeof(uint32_t) * F * nblk_cap);
+    WS_ALLOC(va.pts, sizeof(float4) * FV);
+    WS_ALLOC(va.key, sizeof(uint32_t) * FV);
+    WS_ALLOC(va.parent, sizeof(uint32_t) * FV);
+    WS_ALLOC(va.csize, sizeof(uint32_t) * FV);
+    WS_ALLOC(va.cbox, sizeof(int32_t) * 6 * FV);
+    WS_ALLOC(va.cclose, sizeof(uint32_t) * FV);
+    WS_ALLOC(d_labels, sizeof(uint32_t) * FV);
+    WS_ALLOC(d_table, sizeof(ClusterRec) * FV);
+    WS_ALLOC(d_cand, sizeof(CandMember) * FV);
+    WS_ALLOC(d_ptrank, sizeof(uint32_t) * static_cast<size_t>(F) * pt_cap);
+    WS_ALLOC(d_stage, sizeof(float) * 5 * static_cast<size_t>(F) * pt_cap);
+    WS_ALLOC(d_packed, sizeof(PackedFrame) * F);
+#undef WS_ALLOC
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
+      return e;
+    h_args.assign(F, FrameArgs{});
+    return hipSuccess;
+  }
+};
+
+struct HostCluster
+{
+  ClusterRec rec;
+  int cclass = VOFOD_CLASS_NONE;
+  bool evaluated = false;
+  vt::Boxes boxes{};
+  float obb_size = NAN;
+};
+
+struct vofod_handle
+{
+  std::mutex mtx;
+  vofod_static_params sp{};
+  vofod_dyn_params dp{};
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  float exclude_center[3], oparea_center[3];
+  uint64_t background_min_sufficient_pts = 0;
+
+  MapGeom mg{};
+  vt::Geom hg{};
+  float *d_map = nullptr, *d_flags = nullptr, *d_ray = nullptr;
+  unsigned long long* d_mapbits = nullptr;
+  unsigned long long* d_counter = nullptr;  // [0] nVoxelsOver, [1..] scratch
+  unsigned long long* h_counter = nullptr;  // pinned
+  bool mapbits_valid = false;
+  float mapbits_thr = 0;
+  uint64_t n_bg_voxels = 0;
+
+  float *d_lut_dirs = nullptr, *d_lut_offs = nullptr;
+  uint8_t* d_mask = nullptr;
+
+  Workspace ws, aux, sepws;
+  bool ray_dirty = false;
+  StencilRow* d_rows = nullptr;
+  CloseRow* d_crows = nullptr;
+  float* d_boxstage = nullptr;
+  size_t boxstage_cap = 0;
+  uint64_t* d_idxstage = nullptr;
+  size_t idxstage_cap = 0;
+  std::vector<CandMemberX> h_members_big;
+
+  bool background_pts_sufficient = false, sure_background_sufficient = false;
+  int detection_its = 0;
+  uint32_t last_detection_id = 0;
+  bool raycast_pending = false;
+  int raycast_start_its = 0;
+  vr::SepState sep;
+  bool sep_pending = false;
+  int sep_start_its = 0;
+};
+
+namespace
+{
+
+// ------------------------------------------------------------------ tables built on the host
+
+// Half stencil of the Euclidean predicate d2 < tol^2 on a lattice of pitch `leaf` whose centre
+// coordinates are bounded by cmax in magnitude.  An offset is "sure" when its nominal squared distance
+// differs from tol^2 by more than the worst float evaluation error, "ambiguous" otherwise.
+int build_cluster_stencil(const float leaf[3], float tol, float cmax, std::vector<StencilRow>& rows, ClusterParams& cp)
+{
+  rows.clear();
+  const float r2f = tol * tol;
+  const double r2 = r2f;
+  int R[3];
+  for (int a = 0; a < 3; a++)
+  {
+    R[a] = static_cast<int>(std::ceil(static_cast<double>(tol) / leaf[a])) + 1;
+    if (R[a] > MAX_R)
+      return VOFOD_ERR_INVALID_ARG;
+  }
+  const double delta = 2.0 * ulp32(cmax);  // error bound of one centre coordinate (two roundings)
+  auto classify = [&](int di, int dj, int dk) -> int {  // 1 sure-in, 0 sure-out, 2 ambiguous
+    const double ex = std::fabs(di) * static_cast<double>(leaf[0]), ey = std::fabs(dj) * static_cast<double>(leaf[1]), ez = std::fabs(dk) * static_cast<double>(leaf[2]);
+    const double D = ex * ex + ey * ey + ez * ez;
+    const double eps = 2.0 * delta + 3.0 * ulp32(static_cast<float>(std::max({ex, ey, ez, 1e-30})));
+    const double E = 2.0 * eps * (ex + ey + ez) + 3.0 * eps * eps + 8.0 * D * 1.2e-7;
+    if (D + E < r2)
+      return 1;
+    if (D - E >= r2)
+      return 0;
+    return 2;
+  };
+  cp.row_gap = -1;
+  for (int dk = 0; dk <= R[2]; dk++)
+    for (int dj = (dk == 0 ? 0 : -R[1]); dj <= R[1]; dj++)
+    {
+      StencilRow row{};
+      row.dj = static_cast<int16_t>(dj);
+      row.dk = static_cast<int16_t>(dk);
+      row.r_sure = -1;
+      row.r_max = -1;
+      row.amb = 0;
+      bool sure_run = true;
+      for (int di = 0; di <= R[0]; di++)
+      {
+        const int c = classify(di, dj, dk);
+        if (c == 1 && sure_run)
+          row.r_sure = static_cast<int16_t>(di);
+        else
+          sure_run = false;
+        if (c == 1 && !sure_run)
+          row.amb |= 1u << di;  // cannot happen for a monotone predicate; evaluate in float to stay safe
+        if (c == 2)
+          row.amb |= 1u << di;
+        if (c != 0)
+          row.r_max = static_cast<int16_t>(di);
+      }
+      if (row.r_max < 0)
+        continue;
+      if (dj == 0 && dk == 0)
+      {
+        if (row.r_max < 1)
+          continue;
+        cp.row_gap = std::max<int>(row.r_sure, 0);
+      }
+      rows.push_back(row);
+    }
+  if (rows.size() > MAX_STENCIL_ROWS)
+    return VOFOD_ERR_INVALID_ARG;
+  cp.n_rows = static_cast<int>(rows.size());
+  cp.r2 = r2f;
+  if (cp.row_gap < 0)
+    cp.row_gap = 0;
+  return VOFOD_OK;
+}
+
+// Rows of hasCloseTo's half-open cube (voxel_map.cpp:380-393), nearest rows first.
+int build_close_rows(float max_dist, float vs_inv, std::vector<CloseRow>& rows)
+{
+  rows.clear();
+  const float max_dist_idx = max_dist * vs_inv;
+  const int d = static_cast<int>(std::ceil(max_dist_idx));
+  if (d > MAX_R || d < 0)
+    return VOFOD_ERR_INVALID_ARG;
+  // int(sqrt(n2)) <= max_dist_idx  <=>  n2 <= n2max, found by direct evaluation of the reference's test
+  for (int dy = -d; dy < d; dy++)
+    for (int dz = -d; dz < d; dz++)
+    {
+      int lo = 1, hi = -1;
+      for (int dx = -d; dx < d; dx++)
+      {
+        const int n2 = dx * dx + dy * dy + dz * dz;
+        const int norm = static_cast<int>(std::sqrt(static_cast<double>(n2)));
+        if (static_cast<float>(norm) <= max_dist_idx)
+        {
+          if (hi < lo)
+            lo = dx;
+          hi = dx;
+        }
+      }
+      if (hi >= lo)
+        rows.push_back(CloseRow{static_cast<int16_t>(dy), static_cast<int16_t>(dz), static_cast<int16_t>(lo), static_cast<int16_t>(hi)});
+    }
+  std::stable_sort(rows.begin(), rows.end(), [](const CloseRow& a, const CloseRow& b) { return a.dy * a.dy + a.dz * a.dz < b.dy * b.dy + b.dz * b.dz; });
+  if (rows.size() > MAX_STENCIL_ROWS)
+    return VOFOD_ERR_INVALID_ARG;
+  return VOFOD_OK;
+}
+
+void fill_grid_params(vofod_handle* h, GridParams& g, const float leaf[3], bool align, const float align_center[3], const Workspace& ws)
+{
+  std::memset(&g, 0, sizeof(g));
+  for (int a = 0; a < 3; a++)
+  {
+    g.leaf[a] = leaf[a];
+    g.inv[a] = 1.0f / leaf[a];
+    g.aco[a] = 0;
+    if (align)
+    {
+      float aco = std::fmod(align_center[a] - leaf[a] / 2, leaf[a]);  // voxel_grid_weighted.cpp:86-97
+      if (aco < 0)
+        aco += leaf[a];
+      g.aco[a] = aco;
+    }
+    g.ex_max[a] = h->exclude_center[a] + h->sp.exclude_size[a] / 2;  // vofod_nodelet.cpp:626-629
+    g.ex_min[a] = h->exclude_center[a] - h->sp.exclude_size[a] / 2;
+    g.op_max[a] = h->oparea_center[a] + h->sp.oparea_size[a] / 2;  // :645-648
+    g.op_min[a] = h->oparea_center[a] - h->sp.oparea_size[a] / 2;
+  }
+  g.align = align;
+  g.words_cap = ws.words_cap;
+  g.vox_cap = ws.vox_cap;
+}
+
+int ensure_boxstage(vofod_handle* h, size_t n)
+{
+  if (n <= h->boxstage_cap)
+    return VOFOD_OK;
+  if (h->d_boxstage)
+    (void)hipFree(h->d_boxstage);
+  h->boxstage_cap = std::max<size_t>(n, 1u << 20);
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_boxstage), h->boxstage_cap * sizeof(float)));
+  return VOFOD_OK;
+}
+
+// read the map cells [lo, lo+n) clipped to the map into a host box
+int read_box(vofod_handle* h, const float* d_map, int lo[3], int hi[3], vt::Box& box)
+{
+  for (int a = 0; a < 3; a++)
+  {
+    lo[a] = std::max(lo[a], 0);
+    hi[a] = std::min(hi[a], h->hg.s[a] - 1);
+    box.lo[a] = lo[a];
+    box.n[a] = std::max(hi[a] - lo[a] + 1, 0);
+  }
+  const size_t n = static_cast<size_t>(box.n[0]) * box.n[1] * box.n[2];
+  box.v.resize(n);
+  if (n == 0)
+    return VOFOD_OK;
+  const int r = ensure_boxstage(h, n);
+  if (r != VOFOD_OK)
+    return r;
+  hipLaunchKernelGGL(k_read_box, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_map, h->mg, lo[0], lo[1], lo[2], box.n[0], box.n[1], box.n[2], h->d_boxstage);
+  HIPCHK(hipMemcpyAsync(box.v.data(), h->d_boxstage, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VOFOD_OK;
+}
+
+int scatter_set(vofod_handle* h, float* d_map, const std::vector<uint64_t>& idx, float value)
+{
+  if (idx.empty())
+    return VOFOD_OK;
+  if (idx.size() > h->idxstage_cap)
+  {
+    if (h->d_idxstage)
+      (void)hipFree(h->d_idxstage);
+    h->idxstage_cap = std::max<size_t>(idx.size(), 1u << 16);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_idxstage), h->idxstage_cap * sizeof(uint64_t)));
+  }
+  HIPCHK(hipMemcpyAsync(h->d_idxstage, idx.data(), idx.size() * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_scatter_set, dim3((idx.size() + 255) / 256), dim3(256), 0, h->stream, d_map, h->d_idxstage, static_cast<uint32_t>(idx.size()), value);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VOFOD_OK;
+}
+
+int fill_map(vofod_handle* h, float* p, float v)
+{
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, h->stream, p, h->mg.n, v);
+  HIPCHK(hipGetLastError());
+  return VOFOD_OK;
+}
+
+// reset() vofod_nodelet.cpp:1610-1632
+int do_reset(vofod_handle* h)
+{
+  int r;
+  if ((r = fill_map(h, h->d_map, h->sp.score_init)) != VOFOD_OK)
+    return r;
+  if ((r = fill_map(h, h->d_flags, 0.0f)) != VOFOD_OK)
+    return r;
+  if ((r = fill_map(h, h->d_ray, 0.0f)) != VOFOD_OK)
+    return r;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->detection_its = 0;
+  h->raycast_pending = false;
+  h->sep_pending = false;
+  h->mapbits_valid = false;
+  return VOFOD_OK;
+}
+
+// stage the columns of one cloud into the workspace if they live on the host; fill FrameArgs
+int stage_cloud(vofod_handle* h, Workspace& ws, uint32_t f, const void* x, const void* y, const void* z, const void* intensity, const void* range, size_t stride,
+                size_t n, int memspace, uint32_t flags, const float* tf)
+{
+  FrameArgs& a = ws.h_args[f];
+  std::memset(&a, 0, sizeof(a));
+  a.n = static_cast<uint32_t>(n);
+  a.flags = flags;
+  if (tf)
+    std::memcpy(a.tf, tf, sizeof(float) * 12);
+  if (memspace == VOFOD_MEM_DEVICE)
+  {
+    a.x = static_cast<const char*>(x);
+    a.y = static_cast<const char*>(y);
+    a.z = static_cast<const char*>(z);
+    a.intensity = static_cast<const char*>(intensity);
+    a.stride = stride;
+    return VOFOD_OK;
+  }
+  float* base = ws.d_stage + static_cast<size_t>(f) * ws.pt_cap * 5;
+  const void* cols[5] = {x, y, z, intensity, range};
+  std::vector<float> tmp;
+  for (int c = 0; c < 5; c++)
+  {
+    if (!cols[c])
+      continue;
+    const void* src = cols[c];
+    if (stride != 4)
+    {
+      tmp.resize(n);
+      for (size_t i = 0; i < n; i++)
+        std::memcpy(&tmp[i], static_cast<const char*>(cols[c]) + i * stride, 4);
+      src = tmp.data();
+    }
+    HIPCHK(hipMemcpyAsync(base + static_cast<size_t>(c) * ws.pt_cap, src, n * 4, hipMemcpyHostToDevice, h->stream));
+    if (stride != 4)
+      HIPCHK(hipStreamSynchronize(h->stream));  // tmp is reused
+  }
+  a.x = reinterpret_cast<const char*>(base);
+  a.y = reinterpret_cast<const char*>(base + ws.pt_cap);
+  a.z = reinterpret_cast<const char*>(base + 2 * static_cast<size_t>(ws.pt_cap));
+  a.intensity = intensity ? reinterpret_cast<const char*>(base + 3 * static_cast<size_t>(ws.pt_cap)) : nullptr;
+  a.stride = 4;
+  return VOFOD_OK;
+}
+
+// kernel chain K1-K6 over frames [0,n): bbox -> lattice -> occupancy bitmap -> ranks -> weighted cloud
+int launch_voxelize(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank, bool two_phase)
+{
+  HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
+  const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
+  hipLaunchKernelGGL(k_init_hdr, dim3(n), dim3(64), 0, h->stream, ws.d_hdrs);
+  hipLaunchKernelGGL(k_bbox, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs);
+  hipLaunchKernelGGL(k_grid, dim3(n), dim3(64), 0, h->stream, g, ws.d_hdrs);
+  if (two_phase)
+    return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
+  HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+  hipLaunchKernelGGL(k_setbits, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
+  hipLaunchKernelGGL(k_scan_a, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+  hipLaunchKernelGGL(k_scan_b, dim3(n), dim3(1024), 0, h->stream, g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
+  hipLaunchKernelGGL(k_emit, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
+  hipLaunchKernelGGL(k_count, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr,
+                     ws.pt_cap);
+  HIPCHK(hipGetLastError());
+  return VOFOD_OK;
+}
+
+int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank)
+{
+  const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
+  HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+  hipLaunchKernelGGL(k_setbits, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
+  hipLaunchKernelGGL(k_scan_a, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+  hipLaunchKernelGGL(k_scan_b, dim3(n), dim3(1024), 0, h->stream, g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
+  hipLaunchKernelGGL(k_emit, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
+  hipLaunchKernelGGL(k_count, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr,
+                     ws.pt_cap);
+  HIPCHK(hipGetLastError());
+  return VOFOD_OK;
+}
+
+// K7: union-find CCL over the occupancy bitmap + flatten
+int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax)
+{
+  std::vector<StencilRow> rows;
+  ClusterParams cp{};
+  const int r = build_cluster_stencil(g.leaf, tol, cmax, rows, cp);
+  if (r != VOFOD_OK)
+  {
+    h->err = "cluster tolerance / leaf ratio exceeds the 63-bit neighbour window";
+    return r;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_rows, rows.data(), sizeof(StencilRow) * rows.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // rows is a local
+  const uint32_t gv = (ws.vox_cap + 255u) / 256u;
+  hipLaunchKernelGGL(k_union, dim3(gv, n), dim3(256), 0, h->stream, g, cp, h->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
+  hipLaunchKernelGGL(k_flatten, dim3(gv, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.va, ws.d_labels);
+  HIPCHK(hipGetLastError());
+  return VOFOD_OK;
+}
+
+// nVoxelsOver + occupancy image of the map, cached while the map and the threshold are unchanged
+int ensure_mapbits(vofod_handle* h, float thr)
+{
+  if (h->mapbits_valid && h->mapbits_thr == thr)
+    return VOFOD_OK;
+  HIPCHK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(k_mapbits, dim3(256 * 8), dim3(256), 0, h->stream, h->d_map, h->mg.n, thr, h->d_mapbits, h->d_counter);
+  HIPCHK(hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  h->mapbits_valid = true;
+  h->mapbits_thr = thr;
+  return VOFOD_OK;  // h_counter is valid after the next stream sync
+}
+
+float map_cmax(const vofod_handle* h)
+{
+  float c = 0;
+  for (int a = 0; a < 3; a++)
+  {
+    c = std::max(c, std::fabs(h->mg.off[a]));
+    c = std::max(c, std::fabs(h->mg.off[a] + h->mg.vs * (a == 0 ? h->mg.sx : a == 1 ? h->mg.sy : h->mg.sz)));
+  }
+  return c + 2 * h->mg.vs;
+}
+
+int raycast_begin_locked(vofod_handle* h, const vofod_scan* scan, const float tf[12]);
+int raycast_finish_locked(vofod_handle* h);
+
+// The body of processMsg (vofod_nodelet.cpp:926-965) for n frames.
+int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, uint32_t n, int flags, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame,
+                   size_t* n_out, vofod_scan_debug* dbg)
+{
+  const vofod_static_params& sp = h->sp;
+  const vofod_dyn_params& dp = h->dp;
+  Workspace& ws = h->ws;
+  if (n == 0)
+  {
+    *n_out = 0;
+    return VOFOD_OK;
+  }
+  if (n > ws.F)
+  {
+    h->err = "batch larger than max_batch_frames";
+    return VOFOD_ERR_CAPACITY;
+  }
+  const size_t npts = static_cast<size_t>(sp.sensor_hrays) * sp.sensor_vrays;
+  for (uint32_t f = 0; f < n; f++)
+  {
+    const vofod_scan& s = scans[f];
+    if (!s.x || !s.y || !s.z)
+      return VOFOD_ERR_INVALID_ARG;
+    if (static_cast<size_t>(s.width) * s.height != npts)  // :895-899
+      return VOFOD_ERR_SIZE_MISMATCH;
+  }
+  const bool no_update = flags & VOFOD_SCAN_NO_MAP_UPDATE;
+  int ret = VOFOD_OK;
+  auto t0 = clk::now();
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (dbg)
+    for (auto& e : ev)
+      HIPCHK(hipEventCreate(&e));
+
+  // ---- stage inputs, K1-K6 (filterAndTransform :621-684)
+  for (uint32_t f = 0; f < n; f++)
+  {
+    const vofod_scan& s = scans[f];
+    const int r = stage_cloud(h, ws, f, s.x, s.y, s.z, nullptr, nullptr, s.stride_bytes, npts, s.memspace, FA_SCAN, tfs + 12 * f);
+    if (r != VOFOD_OK)
+      return r;
+  }
+  GridParams g;
+  const float leaf[3] = {sp.voxel_size, sp.voxel_size, sp.voxel_size};
+  const int zero[3] = {0, 0, 0};
+  float align_center[3];
+  h->hg.idxToCoord(zero, align_center);  // :664
+  fill_grid_params(h, g, leaf, true, align_center, ws);
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[0], h->stream));
+  int r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false);
+  if (r != VOFOD_OK)
+    return r;
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[1], h->stream));
+
+  // ---- K7 clusterCloud :932
+  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h));
+  if (r != VOFOD_OK)
+    return r;
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[2], h->stream));
+
+  // ---- K8/K9 findCloseFarClusters :703-750
+  const float thr_new = static_cast<float>(dp.voxel_map__thresholds__new_obstacles);
+  r = ensure_mapbits(h, thr_new);
+  if (r != VOFOD_OK)
+    return r;
+  std::vector<CloseRow> crows;
+  r = build_close_rows(static_cast<float>(dp.ground_points_max_distance), h->mg.vs_inv, crows);
+  if (r != VOFOD_OK)
+  {
+    h->err = "ground_points_max_distance / voxel_size exceeds the 63-bit window";
+    return r;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_crows, crows.data(), sizeof(CloseRow) * crows.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  CloseParams cpar{static_cast<int>(crows.size()), thr_new};
+  const uint32_t gv = (ws.vox_cap + 255u) / 256u;
+  hipLaunchKernelGGL(k_closefar, dim3(gv, n), dim3(256), 0, h->stream, g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[3], h->stream));
+
+  // ---- K10 updateVMaps :943-950 + cluster table + candidate members
+  UpdateParams up{};
+  up.score_point = static_cast<float>(dp.voxel_map__scores__point);
+  up.score_unknown = static_cast<float>(dp.voxel_map__scores__unknown);
+  up.min_points = dp.classification__min_points;
+  up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
+  up.no_update = no_update;
+  hipLaunchKernelGGL(k_finalize, dim3(gv, n), dim3(256), 0, h->stream, g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand);
+  hipLaunchKernelGGL(k_pack, dim3((std::max(SPEC_C, SPEC_M) + 255) / 256, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
+  HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[4], h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!no_update)
+    h->mapbits_valid = false;
+
+  h->n_bg_voxels = h->h_counter[0];
+  if (h->n_bg_voxels > h->background_min_sufficient_pts)  // :716-721
+    h->background_pts_sufficient = true;
+  if (!no_update)
+  {
+    h->detection_its++;  // :949
+    if (flags & VOFOD_SCAN_AUTO_RAYCAST)
+    {
+      if (h->raycast_pending)
+        raycast_finish_locked(h);
+      else
+        raycast_begin_locked(h, &scans[0], tfs);
+    }
+  }
+  double dev_ms[5] = {0, 0, 0, 0, 0};
+  if (dbg)
+  {
+    for (int i = 0; i < 4; i++)
+    {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      dev_ms[i] = ms;
+    }
+    for (auto& e : ev)
+      (void)hipEventDestroy(e);
+  }
+
+  // ---- host tail: classifyClusters :961 + extractDetections :963 per frame
+  const auto t_tail = clk::now();
+  size_t total = 0;
+  const float thr_frontiers = static_cast<float>(dp.voxel_map__thresholds__frontiers);
+  for (uint32_t f = 0; f < n; f++)
+  {
+    const PackedFrame& pf = ws.h_packed[f];
+    const FrameHdr& hdr = pf.hdr;
+    if (hdr.status != VOFOD_OK)
+      ret = hdr.status;
+    // cluster table
+    std::vector<ClusterRec> recs(hdr.C);
+    if (hdr.C <= SPEC_C)
+      std::copy(pf.table, pf.table + hdr.C, recs.begin());
+    else
+    {
+      HIPCHK(hipMemcpy(recs.data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
+    }
+    const CandMemberX* members = pf.members;
+    if (hdr.n_cand > SPEC_M)
+    {
+      h->h_members_big.resize(hdr.n_cand);
+      CandMemberX* d_tmp = nullptr;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_tmp), sizeof(CandMemberX) * hdr.n_cand));
+      hipLaunchKernelGGL(k_gather_members, dim3((hdr.n_cand + 255) / 256), dim3(256), 0, h->stream, g, f, hdr.n_cand, ws.d_cand, ws.va, d_tmp);
+      HIPCHK(hipMemcpyAsync(h->h_members_big.data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      (void)hipFree(d_tmp);
+      members = h->h_members_big.data();
+    }
+    // canonical order: size desc, smallest member asc
+    std::vector<HostCluster> cl(hdr.C);
+    for (uint32_t c = 0; c < hdr.C; c++)
+      cl[c].rec = recs[c];
+    std::sort(cl.begin(), cl.end(), [](const HostCluster& a, const HostCluster& b) {
+      if (a.rec.size != b.rec.size)
+        return a.rec.size > b.rec.size;
+      return a.rec.root < b.rec.root;
+    });
+    std::map<uint32_t, std::vector<vt::Member>> by_root;
+    for (uint32_t i = 0; i < hdr.n_cand; i++)
+    {
+      const CandMemberX& m = members[i];
+      by_root[m.root].push_back(vt::Member{m.v, {m.x, m.y, m.z}, m.count});
+    }
+    for (auto& kv : by_root)
+      std::sort(kv.second.begin(), kv.second.end(), [](const vt::Member& a, const vt::Member& b) { return a.v < b.v; });
+
+    std::vector<uint64_t> pending;  // voxels this scan's classification turned into frontiers (:1712-1715)
+    const float* tf = tfs + 12 * f;
+    const float tpos[3] = {tf[3], tf[7], tf[11]};
+    uint32_t n_det_frame = 0;
+    // classify_cluster :1648-1730 for every far cluster, in order
+    for (HostCluster& c : cl)
+    {
+      if (c.rec.close)
+        continue;
+      c.cclass = VOFOD_CLASS_INVALID;
+      if (!c.rec.cand)
+        continue;  // fails min_points or cannot pass max_size (device-side gate)
+      const std::vector<vt::Member>& mem = by_root[c.rec.root];
+      c.boxes = vt::boxes_of(mem);
+      c.evaluated = true;
+      if (static_cast<int>(mem.size()) < dp.classification__min_points)
+        continue;
+      {
+        const float d[3] = {tpos[0] - c.boxes.obb_center[0], tpos[1] - c.boxes.obb_center[1], tpos[2] - c.boxes.obb_center[2]};
+        const double dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (dist > dp.classification__max_distance)
+          continue;
+      }
+      {
+        const float d[3] = {c.boxes.obb_max[0] - c.boxes.obb_min[0], c.boxes.obb_max[1] - c.boxes.obb_min[1], c.boxes.obb_max[2] - c.boxes.obb_min[2]};
+        c.obb_size = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (c.obb_size > dp.classification__max_size)
+          continue;
+      }
+      bool is_floating = true;
+      if (h->background_pts_sufficient && h->sure_background_sufficient)
+      {
+        const int R = static_cast<int>((c.obb_size + dp.classification__max_explore_distance) / sp.voxel_size);
+        // one read-back covering every member's Manhattan ball
+        int lo[3], hi[3];
+        for (int a = 0; a < 3; a++)
+        {
+          lo[a] = INT32_MAX;
+          hi[a] = INT32_MIN;
+        }
+        for (const vt::Member& m : mem)
+        {
+          int o[3];
+          h->hg.coordToIdx(m.p, o);
+          for (int a = 0; a < 3; a++)
+          {
+            lo[a] = std::min(lo[a], o[a] - R - 1);
+            hi[a] = std::max(hi[a], o[a] + R + 1);
+          }
+        }
+        vt::Box box;
+        r = read_box(h, h->d_map, lo, hi, box);
+        if (r != VOFOD_OK)
+          return r;
+        for (const uint64_t li : pending)
+        {
+          const int i3[3] = {static_cast<int>(li % h->hg.s[0]), static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]), static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]))};
+          if (box.has(i3))
+            box.v[box.at(i3)] = thr_frontiers;
+        }
+        std::vector<uint64_t> explored;
+        for (const vt::Member& m : mem)
+        {
+          const bool connected = vt::explore_to_ground(h->hg, box, m.p, thr_frontiers, thr_new, static_cast<float>(R), explored);
+          if (connected)
+          {
+            is_floating = false;
+            break;
+          }
+          for (const uint64_t li : explored)
+          {
+            const int i3[3] = {static_cast<int>(li % h->hg.s[0]), static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]), static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]))};
+            box.v[box.at(i3)] = thr_frontiers;
+            pending.push_back(li);
+          }
+        }
+      }
+      else
+        is_floating = false;
+      c.cclass = is_floating ? VOFOD_CLASS_MAV : VOFOD_CLASS_UNKNOWN;
+    }
+    // extractDetections :834-879
+    for (HostCluster& c : cl)
+    {
+      if (c.rec.close || c.cclass != VOFOD_CLASS_MAV)
+        continue;
+      const std::vector<vt::Member>& mem = by_root[c.rec.root];
+      vofod_detection det{};
+      const float d[3] = {tpos[0] - c.boxes.obb_center[0], tpos[1] - c.boxes.obb_center[1], tpos[2] - c.boxes.obb_center[2]};
+      const double det_dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      det.id = h->last_detection_id++;
+      det.frame = f;
+      det.n_points = mem.size();
+      const float cov = static_cast<float>(std::sqrt(det_dist) * dp.output__position_sigma);
+      for (int q = 0; q < 3; q++)
+        det.covariance[4 * q] = cov;
+      // getSubmapCopy(aabb, inflate 2) voxel_map.cpp:547-584
+      int mn[3], mx[3];
+      h->hg.coordToIdx(c.boxes.aabb_min, mn);
+      h->hg.coordToIdx(c.boxes.aabb_max, mx);
+      for (int a = 0; a < 3; a++)
+      {
+        mn[a] = std::clamp(mn[a] - 2, 0, h->hg.s[a] - 1);
+        mx[a] = std::clamp(mx[a] + 2, 0, h->hg.s[a] - 1);
+      }
+      vt::Box sub;
+      r = read_box(h, h->d_map, mn, mx, sub);
+      if (r != VOFOD_OK)
+        return r;
+      for (const uint64_t li : pending)
+      {
+        const int i3[3] = {static_cast<int>(li % h->hg.s[0]), static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]), static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]))};
+        if (sub.has(i3))
+          sub.v[sub.at(i3)] = thr_frontiers;
+      }
+      vt::Geom sg = h->hg;  // the sub-map's own geometry: offset = idxToCoord(min) - vs/2 (:563)
+      float cmin[3];
+      h->hg.idxToCoord(mn, cmin);
+      for (int a = 0; a < 3; a++)
+      {
+        sg.off[a] = cmin[a] - h->hg.vs / 2.0f;
+        sg.s[a] = sub.n[a];
+      }
+      const float ray = static_cast<float>(dp.voxel_map__scores__ray);
+      for (const vt::Member& m : mem)
+      {
+        int si[3];
+        sg.coordToIdx(m.p, si);
+        if (sg.inLimits(si))
+          sub.v[(static_cast<size_t>(si[2]) * sub.n[1] + si[1]) * sub.n[0] + si[0]] = ray;  // :853-857
+      }
+      double u = 0.0;
+      for (const float val : sub.v)
+        u += 1.0 - val / dp.voxel_map__scores__ray;  // :860-862
+      u /= mem.size();
+      det.confidence = static_cast<float>(1.0 / std::exp(u));
+      const double vray_res = sp.sensor_vfov / static_cast<double>(sp.sensor_vrays);
+      const double hray_res = 2 * M_PI / static_cast<double>(sp.sensor_hrays);
+      det.detection_probability = std::min(std::atan(1.0 / det_dist) / (vray_res * dp.classification__min_points), 1.0) * std::min(std::atan(1.0 / det_dist) / hray_res, 1.0);
+      for (int a = 0; a < 3; a++)
+        det.position[a] = c.boxes.obb_center[a];
+      if (out && total < cap)
+        out[total] = det;
+      total++;
+      n_det_frame++;
+    }
+    if (n_out_per_frame)
+      n_out_per_frame[f] = n_det_frame;
+    if (!no_update && !pending.empty())
+    {
+      r = scatter_set(h, h->d_map, pending, thr_frontiers);
+      if (r != VOFOD_OK)
+        return r;
+      h->mapbits_valid = false;
+    }
+
+    if (dbg)
+    {
+      vofod_scan_debug& d = dbg[f];
+      d.n_input_after_crop = hdr.n_in;
+      d.n_bg_voxels = h->n_bg_voxels;
+      d.background_pts_sufficient = h->background_pts_sufficient;
+      d.sure_background_sufficient = h->sure_background_sufficient;
+      d.n_weighted = hdr.V;
+      d.n_clusters = hdr.C;
+      if ((d.weighted || d.labels) && d.weighted_cap < hdr.V)
+        ret = VOFOD_ERR_CAPACITY;
+      else
+      {
+        if (d.weighted && hdr.V)
+          HIPCHK(hipMemcpy(d.weighted, ws.va.pts + static_cast<size_t>(f) * ws.vox_cap, sizeof(float4) * hdr.V, hipMemcpyDeviceToHost));
+        if (d.labels && hdr.V)
+          HIPCHK(hipMemcpy(d.labels, ws.d_labels + static_cast<size_t>(f) * ws.vox_cap, sizeof(uint32_t) * hdr.V, hipMemcpyDeviceToHost));
+      }
+      if (d.clusters)
+      {
+        if (d.clusters_cap < hdr.C)
+          ret = VOFOD_ERR_CAPACITY;
+        else
+          for (uint32_t c = 0; c < hdr.C; c++)
+          {
+            const HostCluster& hc = cl[c];
+            vofod_cluster_info& ci = d.clusters[c];
+            ci.first_member = hc.rec.root;
+            ci.n_points = hc.rec.size;
+            ci.is_close = hc.rec.close;
+            ci.cclass = hc.cclass;
+            for (int a = 0; a < 3; a++)
+            {
+              ci.aabb_min[a] = (static_cast<float>(hc.rec.imin[a]) + 0.5f) * g.leaf[a] + hdr.offset[a];
+              ci.aabb_max[a] = (static_cast<float>(hc.rec.imax[a]) + 0.5f) * g.leaf[a] + hdr.offset[a];
+              ci.obb_center[a] = hc.evaluated ? hc.boxes.obb_center[a] : NAN;
+            }
+            ci.obb_size = hc.obb_size;
+          }
+      }
+      d.stage_ms[0] = dev_ms[0];
+      d.stage_ms[1] = dev_ms[1];
+      d.stage_ms[2] = dev_ms[2];
+      d.stage_ms[3] = dev_ms[3];
+      d.stage_ms[4] = ms_since(t_tail);
+      d.stage_ms[5] = ms_since(t0);
+    }
+  }
+  *n_out = total;
+  if (total > cap)
+    ret = VOFOD_ERR_CAPACITY;
+  return ret;
+}
+
+}  // namespace
+
+#include "driver_aux.h"

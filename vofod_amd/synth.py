@@ -164,3 +164,34 @@ def apriori_points(scene: Scene, voxel_size: float, n_voxels: int | None = None,
     if n_voxels is not None and p.shape[0] > n_voxels:
         p = p[rng.choice(p.shape[0], size=n_voxels, replace=False)]
     return p.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------- scenarios
+
+def seed_ground(det, xy=(0.0, 0.0), radius: float = 3.0, value: float = -185.0):
+    """Stand-in for the range-finder ground seeding of processMsg(Range) (vofod_nodelet.cpp:581-613,
+    out of scope here): marks the ground voxels under the sensor as background so that the first
+    scans have something to be 'close' to.  Works on any implementation of the C-ABI."""
+    from . import capi
+
+    m = det.read_map(capi.MAP_VOXELS)
+    sx, sy, sz = det.map_size
+    ox, oy, oz = det.map_offset
+    vs = float(det.sp.voxel_size)
+    iz = int(np.floor((0.0 - oz) / vs))
+    r = int(np.ceil(radius / vs))
+    cx, cy = int(np.floor((xy[0] - ox) / vs)), int(np.floor((xy[1] - oy) / vs))
+    x0, x1 = max(cx - r, 0), min(cx + r + 1, sx)
+    y0, y1 = max(cy - r, 0), min(cy + r + 1, sy)
+    if 0 <= iz < sz:
+        m[iz, y0:y1, x0:x1] = value
+    det.write_map(capi.MAP_VOXELS, m)
+
+
+def scan_sequence(scene: Scene, sensor: str, n: int, seed0: int = 0, xy=(0.0, 0.0)):
+    """n scans of one scene from slowly varying poses (a hovering MAV)."""
+    out = []
+    for k in range(n):
+        tf = make_pose(seed0 + k, xy=xy)
+        out.append(make_scan(scene, tf, sensor, seed=seed0 + k))
+    return out
