@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py — LiDAR frames/s of the per-scan hot path on MI355X (BASELINE.json metric).
+
+A step = one `vofod_process_batch` call over F independent synthetic OS1-128 scans (131 072 points each,
+0.25 m voxels: BASELINE.json configs[1] in the batched form of configs[3]) against a pre-warmed voxel map,
+inputs already resident in HBM.  With N GPUs every rank processes its own F frames per step (weak scaling,
+no data-path collective) and the fixed-size detection records are all-gathered with RCCL at the end of
+each step.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="independent scans per GPU per step")
+    ap.add_argument("--voxel-size", type=float, default=0.25)
+    ap.add_argument("--sensor", default="os1-128")
+    ap.add_argument("--map-warm-scans", type=int, default=20)
+    ap.add_argument("--cpu-baseline-scans", type=int, default=8, help="scans timed through the CPU oracle (0 disables)")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    return ap.parse_args()
+
+
+def build_detector(lib, sensor, voxel_size, frames, device):
+    from vofod_amd import synth
+    from vofod_amd.detector import VoFOD, default_params
+
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(lib)
+    sp.voxel_size = voxel_size
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    sp.max_batch_frames = frames
+    sp.device = device
+    return VoFOD(lib, sp, dp)
+
+
+def warm_map(det, scene, sensor, n_scans, seed0):
+    """config 2 of SURVEY 8d: map pre-warmed by n scans with the raycast and sepclusters roles interleaved."""
+    from vofod_amd import capi, synth
+
+    synth.seed_ground(det)
+    scans = synth.scan_sequence(scene, sensor, n_scans, seed0=seed0)
+    for k, s in enumerate(scans):
+        det.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+        if k % 2 == 1:
+            st, sure = det.sepclusters_begin(allow=(capi.ERR_EMPTY,))
+            if st == capi.OK and sure:
+                det.sepclusters_finish()
+    if det.status().raycast_pending:
+        det.raycast_finish(allow=(capi.ERR_RAYCAST_NO_DETECTION, capi.ERR_RAYCAST_EMPTY))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vofod_amd
+    from vofod_amd import capi, synth
+    from vofod_amd.detector import ScanData
+
+    lib = vofod_amd.library()
+    F = args.frames
+    det = build_detector(lib, args.sensor, args.voxel_size, F, local_rank)
+    scene = synth.make_scene(0, n_targets=3)
+    warm_map(det, scene, args.sensor, args.map_warm_scans, seed0=1000)
+
+    # F independent frames per rank (seeds differ per rank), resident in HBM as packed SoA columns
+    h, w, _, _ = synth.SENSORS[args.sensor]
+    n_pts = h * w
+    host_scans = [synth.make_scan(scene, synth.make_pose(10_000 * rank + f), args.sensor, seed=10_000 * rank + f) for f in range(F)]
+    cols = torch.empty((F, 3, n_pts), dtype=torch.float32, device=dev)
+    for f, s in enumerate(host_scans):
+        cols[f, 0] = torch.from_numpy(s.x)
+        cols[f, 1] = torch.from_numpy(s.y)
+        cols[f, 2] = torch.from_numpy(s.z)
+    torch.cuda.synchronize()
+    scans = [
+        ScanData(x=cols[f, 0].data_ptr(), y=cols[f, 1].data_ptr(), z=cols[f, 2].data_ptr(), width=w, height=h, stride_bytes=4, memspace=capi.MEM_DEVICE)
+        for f in range(F)
+    ]
+    tfs = np.stack([s.tf for s in host_scans]).astype(np.float32)
+
+    D_MAX = 16  # detection records per frame in the all-gather payload
+    rec_local = torch.zeros((F, D_MAX * 16 + 1), dtype=torch.float64, device=dev)  # 128-B records + per-frame count
+    rec_all = torch.zeros((world, F, D_MAX * 16 + 1), dtype=torch.float64, device=dev) if world > 1 else None
+    rec_host = np.zeros((F, D_MAX * 16 + 1), dtype=np.float64)
+
+    def step():
+        dets, per = det.process_batch(scans, tfs)
+        if world > 1:
+            rec_host[:] = 0
+            rec_host[:, -1] = per
+            k0 = 0
+            for f in range(F):
+                for j in range(min(int(per[f]), D_MAX)):
+                    rec_host[f, 16 * j : 16 * j + 16] = np.frombuffer(dets[k0 + j].tobytes(), dtype=np.float64)
+                k0 += int(per[f])
+            rec_local.copy_(torch.from_numpy(rec_host))
+            dist.all_gather_into_tensor(rec_all, rec_local)
+        return dets, per
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    n_det = 0
+    for _ in range(args.steps):
+        dets, per = step()
+        n_det += len(dets)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        frames = world * F * args.steps
+        # per-frame statistics for the algorithmic-bytes model B = 12*N + 40*V
+        _, dbg = det.process_scan(scans[0], tfs[0], flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+        V = len(dbg["weighted"])
+        out = {
+            "metric": "LiDAR frames/sec (131k-pt OS1-128) at 1/2/4/8 MI355X + HBM roofline %",
+            "value": frames / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.sensor} {h}x{w} scans, {args.voxel_size} m voxels, batched process_scan (configs[1] scan shape in configs[3]'s batched form)",
+                "frames_per_gpu_per_step": F,
+                "points_per_frame": n_pts,
+                "voxels_per_frame": V,
+                "map_voxels": det.n_voxels,
+                "map_warm_scans": args.map_warm_scans,
+                "detections_per_step": n_det / args.steps,
+            },
+        }
+        # single-stream (stateful, sequential) latency of the same scan shape
+        seq = synth.scan_sequence(scene, args.sensor, 6, seed0=5000)
+        seq_dev = []
+        keep = []
+        for s in seq:
+            t = torch.from_numpy(np.stack([s.x, s.y, s.z])).to(dev)
+            keep.append(t)
+            seq_dev.append(ScanData(x=t[0].data_ptr(), y=t[1].data_ptr(), z=t[2].data_ptr(), width=w, height=h, stride_bytes=4, memspace=capi.MEM_DEVICE))
+        torch.cuda.synchronize()
+        det.process_scan(seq_dev[0], seq[0].tf)
+        t1 = time.perf_counter()
+        for s, sd in zip(seq[1:], seq_dev[1:]):
+            det.process_scan(sd, s.tf)
+        single_ms = 1e3 * (time.perf_counter() - t1) / (len(seq) - 1)
+        out["single_stream"] = {"ms_per_scan": single_ms, "frames_per_s": 1e3 / single_ms, "note": "sequential vofod_process_scan with map update, device-resident input"}
+
+        if not args.no_profile_pass:
+            out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F)
+        if args.cpu_baseline_scans > 0:
+            out["cpu_baseline"] = cpu_baseline(args, scene, host_scans)
+    sync()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def profile_pass(lib, det, scans, tfs, n_pts, V, F):
+    """Per-kernel device time measured with HIP events on the library's own stream (vofod_profile_*)."""
+    from vofod_amd import capi
+
+    lib.profile_enable(det.h, 1)
+    reps = 5
+    for _ in range(reps):
+        det.process_batch(scans, tfs)
+    names = (C.c_char * (64 * 64))()
+    ms = (C.c_double * 64)()
+    calls = (C.c_uint64 * 64)()
+    n = lib.profile_read(det.h, names, ms, calls, 64)
+    lib.profile_enable(det.h, 0)
+    kernels = {}
+    for i in range(n):
+        nm = names[64 * i : 64 * i + 64].split(b"\0", 1)[0].decode()
+        kernels[nm] = {"avg_us": 1e3 * ms[i] / max(calls[i], 1), "launches": int(calls[i])}
+    # algorithmic bytes per launch: every launch covers F frames
+    M = det.n_voxels
+    alg = {
+        "k_bbox": 12.0 * n_pts * F,
+        "k_setbits": 12.0 * n_pts * F,
+        "k_count": 12.0 * n_pts * F,
+        "k_emit": 20.0 * V * F,
+        "k_union": 20.0 * V * F,
+        "k_flatten": 8.0 * V * F,
+        "k_closefar": 4.0 * V * F,
+        "k_finalize": 12.0 * V * F,
+        "k_mapbits": 4.0 * M + M / 8.0,
+    }
+    for nm, k in kernels.items():
+        if nm in alg and k["avg_us"] > 0:
+            k["alg_bytes"] = alg[nm]
+            k["GBps"] = alg[nm] / (k["avg_us"] * 1e-6) / 1e9
+    path = ["k_bbox", "k_grid", "k_setbits", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten"]
+    path_us = sum(kernels[p]["avg_us"] for p in path if p in kernels)
+    dom = max((p for p in path if p in kernels), key=lambda p: kernels[p]["avg_us"])
+    dk = kernels[dom]
+    roofline = {
+        "bound": "hbm",
+        "kernel": dom,
+        "achieved": dk.get("GBps", 0.0),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": dk.get("GBps", 0.0) / HBM_PEAK_GBS,
+        "traffic": None,
+        "alg_bytes_per_launch": dk.get("alg_bytes"),
+        "avg_launch_us": dk["avg_us"],
+        "path": {
+            "what": "voxelize+cluster path, B = (12*N + 40*V) per frame (SURVEY 8d) over the summed kernel time of one batch",
+            "alg_bytes_per_batch": (12.0 * n_pts + 40.0 * V) * F,
+            "device_us_per_batch": path_us,
+            "GBps": (12.0 * n_pts + 40.0 * V) * F / (path_us * 1e-6) / 1e9 if path_us else 0.0,
+            "frac": (12.0 * n_pts + 40.0 * V) * F / (path_us * 1e-6) / 1e9 / HBM_PEAK_GBS if path_us else 0.0,
+        },
+    }
+    return roofline, kernels
+
+
+def cpu_baseline(args, scene, host_scans):
+    """The CPU oracle ("port": restatement of the reference algorithm, 1 thread as pointcloud_threads: 1) timed on
+    a bounded sample of the same workload."""
+    from vofod_amd import capi
+
+    so = ROOT / "oracle" / "libvofod_oracle.so"
+    olib = capi.Library(so, "vofod_oracle_")
+    det = build_detector(olib, args.sensor, args.voxel_size, 1, 0)
+    warm_map(det, scene, args.sensor, min(args.map_warm_scans, 6), seed0=1000)
+    n = min(args.cpu_baseline_scans, len(host_scans))
+    t0 = time.perf_counter()
+    for s in host_scans[:n]:
+        det.process_scan(s.scan, s.tf, flags=capi.SCAN_NO_MAP_UPDATE)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} of the benchmark's OS1-128 scans through the C++ CPU oracle (restatement of the reference algorithm, not the PCL build), "
+        f"map warmed by {min(args.map_warm_scans, 6)} scans, host has {os.cpu_count()} cores",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -300,6 +300,15 @@ int vofod_load_cloud(const char* filename, float* xyz, size_t cap, size_t* n_out
 /* simulated sensor LUT of initialize_sensor_lut_simulation (vofod_nodelet.cpp:374-420) */
 int vofod_sim_lut(int32_t w, int32_t h, float vfov, float* directions /* 3*w*h */);
 
+/* ------------------------------------------------------------ diagnostics */
+
+/* Per-kernel device time, measured with HIP events on the handle's own stream (the reference analogue is
+ * mrs_lib::ScopeTimer, vofod_nodelet.cpp:887,1135,1426).  While enabled every kernel launch is bracketed by
+ * two events; vofod_profile_read drains them: names[64*i..] = kernel name, ms[i] = summed time, calls[i] =
+ * launches.  Returns the number of distinct kernels.  No-ops in the oracle. */
+int vofod_profile_enable(vofod_handle* h, int on);
+size_t vofod_profile_read(vofod_handle* h, char* names, double* ms, uint64_t* calls, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

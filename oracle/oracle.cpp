@@ -1021,6 +1021,9 @@ int ORACLE_API(sim_lut)(int32_t w, int32_t h, float vfov, float* directions)
   return VOFOD_OK;
 }
 
+int ORACLE_API(profile_enable)(vofod_handle*, int) { return VOFOD_OK; }
+size_t ORACLE_API(profile_read)(vofod_handle*, char*, double*, uint64_t*, size_t) { return 0; }
+
 // ---- direct VoxelMap access for the known-answer tests (tests/test_oracle_kat.py)
 int vofod_oracle_map_has_close_to(vofod_handle* h, float x, float y, float z, float max_dist, float thr) { return h->vmap.hasCloseTo(x, y, z, max_dist, thr); }
 

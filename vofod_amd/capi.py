@@ -237,6 +237,8 @@ _SIGS = {
     "cluster": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(GridDesc), C.c_size_t, C.c_float, C.c_void_p, _P(C.c_size_t)]),
     "load_cloud": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "sim_lut": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "profile_read": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
 

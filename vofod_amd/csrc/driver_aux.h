@@ -15,9 +15,9 @@ int gscan(vofod_handle* h, const uint32_t* d_in, uint32_t n, uint32_t* d_out, ui
       HIPCHK(hipMemsetAsync(d_total, 0, sizeof(uint32_t), h->stream));
     return VOFOD_OK;
   }
-  hipLaunchKernelGGL(vr::k_gscan_a, dim3(nblk), dim3(256), 0, h->stream, d_in, n, d_bsum);
-  hipLaunchKernelGGL(vr::k_gscan_b, dim3(1), dim3(1024), 0, h->stream, d_bsum, nblk, d_total);
-  hipLaunchKernelGGL(vr::k_gscan_c, dim3(nblk), dim3(256), 0, h->stream, d_in, n, d_bsum, d_out);
+  KLAUNCH(h, vr::k_gscan_a, dim3(nblk), dim3(256), d_in, n, d_bsum);
+  KLAUNCH(h, vr::k_gscan_b, dim3(1), dim3(1024), d_bsum, nblk, d_total);
+  KLAUNCH(h, vr::k_gscan_c, dim3(nblk), dim3(256), d_in, n, d_bsum, d_out);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -126,8 +126,7 @@ int raycast_begin_locked(vofod_handle* h, const vofod_scan* scan, const float tf
   h->hg.coordToIdx(rp.origin, o);
   int ret = VOFOD_OK;
   if (h->hg.inLimits(o))  // :1432
-    hipLaunchKernelGGL(vr::k_raycast, dim3((n + 255) / 256), dim3(256), 0, h->stream, rp, h->mg, d_int, d_rng, stride, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_ray,
-                       reinterpret_cast<uint32_t*>(h->d_counter + 1));
+    KLAUNCH(h, vr::k_raycast, dim3((n + 255) / 256), dim3(256), rp, h->mg, d_int, d_rng, stride, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_ray, reinterpret_cast<uint32_t*>(h->d_counter + 1));
   else
     ret = VOFOD_ERR_SENSOR_OUTSIDE_MAP;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -158,13 +157,13 @@ int raycast_finish_locked(vofod_handle* h)
   if (!sp.new_rule)
   {
     HIPCHK(hipMemsetAsync(h->d_counter + 2, 0, sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(vr::k_max_nonneg, dim3(2048), dim3(256), 0, h->stream, h->d_ray, h->mg.n, reinterpret_cast<uint32_t*>(h->d_counter + 2));
+    KLAUNCH(h, vr::k_max_nonneg, dim3(2048), dim3(256), h->d_ray, h->mg.n, reinterpret_cast<uint32_t*>(h->d_counter + 2));
     HIPCHK(hipMemcpyAsync(h->h_counter + 2, h->d_counter + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const uint32_t bits = static_cast<uint32_t>(h->h_counter[2]);
     std::memcpy(&sp.max_val, &bits, 4);
   }
-  hipLaunchKernelGGL(vr::k_ray_sweep, dim3(256 * 8), dim3(256), 0, h->stream, sp, h->mg.n, h->d_map, h->d_flags, h->d_ray);
+  KLAUNCH(h, vr::k_ray_sweep, dim3(256 * 8), dim3(256), sp, h->mg.n, h->d_map, h->d_flags, h->d_ray);
   HIPCHK(hipStreamSynchronize(h->stream));
   h->ray_dirty = false;
   h->mapbits_valid = false;
@@ -180,11 +179,11 @@ int counted_tail(vofod_handle* h, Workspace& ws, uint32_t V, uint32_t P, const u
   int r = gscan(h, d_sure_flags, P, s.d_sure_pre, s.d_bsum, nullptr);
   if (r != VOFOD_OK)
     return r;
-  hipLaunchKernelGGL(vr::k_voxel_counts, dim3((V + 255) / 256), dim3(256), 0, h->stream, ws.d_hdrs, ws.va.pts, s.d_vcnt);
+  KLAUNCH(h, vr::k_voxel_counts, dim3((V + 255) / 256), dim3(256), ws.d_hdrs, ws.va.pts, s.d_vcnt);
   r = gscan(h, s.d_vcnt, V, s.d_first, s.d_bsum, nullptr);
   if (r != VOFOD_OK)
     return r;
-  hipLaunchKernelGGL(vr::k_counted_range, dim3((V + 255) / 256), dim3(256), 0, h->stream, ws.d_hdrs, s.d_first, s.d_sure_pre, P, ws.va.pts);
+  KLAUNCH(h, vr::k_counted_range, dim3((V + 255) / 256), dim3(256), ws.d_hdrs, s.d_first, s.d_sure_pre, P, ws.va.pts);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -267,8 +266,8 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
     return r;
   if ((r = sep_ensure_pts(h, 1 << 16)) != VOFOD_OK)
     return r;
-  hipLaunchKernelGGL(vr::k_transpose_bits, dim3(256 * 8), dim3(256), 0, h->stream, h->mg, h->d_mapbits, s.d_tbits);
-  hipLaunchKernelGGL(vr::k_popc_words, dim3((n_words + 255) / 256), dim3(256), 0, h->stream, s.d_tbits, n_words, s.d_tpop);
+  KLAUNCH(h, vr::k_transpose_bits, dim3(256 * 8), dim3(256), h->mg, h->d_mapbits, s.d_tbits);
+  KLAUNCH(h, vr::k_popc_words, dim3((n_words + 255) / 256), dim3(256), s.d_tbits, n_words, s.d_tpop);
   if (s.pts_cap / vr::GS_EPB + 1024 < n_words / vr::GS_EPB + 2)
     if ((r = sep_ensure_pts(h, static_cast<size_t>(n_words))) != VOFOD_OK)
       return r;
@@ -282,8 +281,7 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
     return VOFOD_ERR_EMPTY;  // :1155-1159
   if ((r = sep_ensure_pts(h, P)) != VOFOD_OK)
     return r;
-  hipLaunchKernelGGL(vr::k_emit_vpc, dim3((n_words + 255) / 256), dim3(256), 0, h->stream, h->mg, h->d_map, s.d_tbits, s.d_tprefix, n_words, thr_sure, s.d_px, s.d_py, s.d_pz,
-                     s.d_pi, s.d_sure);
+  KLAUNCH(h, vr::k_emit_vpc, dim3((n_words + 255) / 256), dim3(256), h->mg, h->d_map, s.d_tbits, s.d_tprefix, n_words, thr_sure, s.d_px, s.d_py, s.d_pz, s.d_pi, s.d_sure);
 
   // K6': VoxelGridCounted with leaf lsz on the index cloud (:1162-1167)
   vofod_cloud_view view{};
@@ -311,8 +309,8 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
   HIPCHK(hipMemsetAsync(s.d_nsure, 0, sizeof(uint32_t) * std::max(hdr.V, 1u), h->stream));
   HIPCHK(hipMemsetAsync(s.d_small + 1, 0, 2 * sizeof(uint32_t), h->stream));
   const uint32_t gv = (hdr.V + 255) / 256;
-  hipLaunchKernelGGL(vr::k_cluster_sure, dim3(gv), dim3(256), 0, h->stream, ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure);
-  hipLaunchKernelGGL(vr::k_any_sure, dim3(gv), dim3(256), 0, h->stream, ws.d_hdrs, ws.d_labels, s.d_nsure, static_cast<uint32_t>(dp.sepclusters__min_sure_points), s.d_small + 1);
+  KLAUNCH(h, vr::k_cluster_sure, dim3(gv), dim3(256), ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure);
+  KLAUNCH(h, vr::k_any_sure, dim3(gv), dim3(256), ws.d_hdrs, ws.d_labels, s.d_nsure, static_cast<uint32_t>(dp.sepclusters__min_sure_points), s.d_small + 1);
   HIPCHK(hipMemcpyAsync(s.h_small, s.d_small, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (s.h_small[1] == 0)
@@ -363,7 +361,7 @@ int sepclusters_finish_locked(vofod_handle* h)
   ep.n_offsets = static_cast<int>(offs.size() / 3);
   Workspace& ws = h->sepws;
   const uint32_t gv = (ws.vox_cap + 255) / 256;
-  hipLaunchKernelGGL(vr::k_sep_erase, dim3(gv), dim3(256), 0, h->stream, ep, h->mg, ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure, s.d_offsets, h->d_map);
+  KLAUNCH(h, vr::k_sep_erase, dim3(gv), dim3(256), ep, h->mg, ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure, s.d_offsets, h->d_map);
   HIPCHK(hipStreamSynchronize(h->stream));
   h->mapbits_valid = false;
   return VOFOD_OK;
@@ -644,7 +642,7 @@ int vofod_load_apriori(vofod_handle* h, const float* xyz, size_t n)
     float* d = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), n * 3 * sizeof(float)));
     HIPCHK(hipMemcpy(d, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_apriori, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_map, h->mg, d, static_cast<uint32_t>(n));
+    KLAUNCH(h, k_apriori, dim3((n + 255) / 256), dim3(256), h->d_map, h->mg, d, static_cast<uint32_t>(n));
     HIPCHK(hipStreamSynchronize(h->stream));
     (void)hipFree(d);
   }
@@ -821,7 +819,7 @@ int vofod_voxel_grid_counted(vofod_handle* h, const vofod_cloud_view* in, float 
   if ((r = sep_ensure_words(h, 1)) != VOFOD_OK || (r = sep_ensure_pts(h, P)) != VOFOD_OK)
     return r;
   const FrameArgs& a = h->aux.h_args[0];
-  hipLaunchKernelGGL(vr::k_flag_over, dim3((P + 255) / 256), dim3(256), 0, h->stream, a.intensity, a.stride, P, threshold, h->sep.d_sure);
+  KLAUNCH(h, vr::k_flag_over, dim3((P + 255) / 256), dim3(256), a.intensity, a.stride, P, threshold, h->sep.d_sure);
   if ((r = counted_tail(h, h->aux, hdr.V, P, h->sep.d_sure)) != VOFOD_OK)
     return r;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -915,6 +913,62 @@ int vofod_cluster(vofod_handle* h, const vofod_point_xyzr* pts, const uint32_t* 
     *n_clusters = c;
   }
   return VOFOD_OK;
+}
+
+int vofod_profile_enable(vofod_handle* h, int on)
+{
+  if (!h)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& r : h->prof.recs)
+  {
+    h->prof.pool.push_back(r.a);
+    h->prof.pool.push_back(r.b);
+  }
+  h->prof.recs.clear();
+  h->prof.on = on != 0;
+  return VOFOD_OK;
+}
+
+size_t vofod_profile_read(vofod_handle* h, char* names, double* ms, uint64_t* calls, size_t cap)
+{
+  if (!h || !names || !ms || !calls)
+    return 0;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<double, uint64_t>> acc;
+  for (auto& r : h->prof.recs)
+  {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    std::string nm = r.name;
+    const size_t c = nm.rfind(':');
+    if (c != std::string::npos)
+      nm = nm.substr(c + 1);
+    if (!acc.count(nm))
+      order.push_back(nm);
+    acc[nm].first += t;
+    acc[nm].second += 1;
+    h->prof.pool.push_back(r.a);
+    h->prof.pool.push_back(r.b);
+  }
+  h->prof.recs.clear();
+  size_t n = 0;
+  for (const auto& nm : order)
+  {
+    if (n >= cap)
+      break;
+    std::memset(names + 64 * n, 0, 64);
+    std::strncpy(names + 64 * n, nm.c_str(), 63);
+    ms[n] = acc[nm].first;
+    calls[n] = acc[nm].second;
+    n++;
+  }
+  return n;
 }
 
 // load_cloud pc_loader.cpp:17-90 (host I/O helper, no device work)

@@ -109,6 +109,46 @@ inline float ulp32(float x)
     }                                                                                                        \
   } while (0)
 
+// ---- optional per-kernel timing with HIP events on the handle's stream (vofod_profile_*) ----------
+struct Prof
+{
+  bool on = false;
+  struct Rec
+  {
+    const char* name;
+    hipEvent_t a, b;
+  };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get()
+  {
+    if (!pool.empty())
+    {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+};
+
+#define KLAUNCH(h, kern, grid, block, ...)                                   \
+  do                                                                         \
+  {                                                                          \
+    if ((h)->prof.on)                                                        \
+    {                                                                        \
+      Prof::Rec r_{#kern, (h)->prof.get(), (h)->prof.get()};                 \
+      (void)hipEventRecord(r_.a, (h)->stream);                               \
+      hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+      (void)hipEventRecord(r_.b, (h)->stream);                               \
+      (h)->prof.recs.push_back(r_);                                          \
+    }                                                                        \
+    else                                                                     \
+      hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+  } while (0)
+
 struct Workspace
 {
   uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0;
@@ -197,6 +237,7 @@ struct vofod_handle
   vofod_static_params sp{};
   vofod_dyn_params dp{};
   std::string err;
+  Prof prof;
   int device = 0;
   hipStream_t stream = nullptr;
 
@@ -398,7 +439,7 @@ int read_box(vofod_handle* h, const float* d_map, int lo[3], int hi[3], vt::Box&
   const int r = ensure_boxstage(h, n);
   if (r != VOFOD_OK)
     return r;
-  hipLaunchKernelGGL(k_read_box, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_map, h->mg, lo[0], lo[1], lo[2], box.n[0], box.n[1], box.n[2], h->d_boxstage);
+  KLAUNCH(h, k_read_box, dim3((n + 255) / 256), dim3(256), d_map, h->mg, lo[0], lo[1], lo[2], box.n[0], box.n[1], box.n[2], h->d_boxstage);
   HIPCHK(hipMemcpyAsync(box.v.data(), h->d_boxstage, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return VOFOD_OK;
@@ -416,14 +457,14 @@ int scatter_set(vofod_handle* h, float* d_map, const std::vector<uint64_t>& idx,
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_idxstage), h->idxstage_cap * sizeof(uint64_t)));
   }
   HIPCHK(hipMemcpyAsync(h->d_idxstage, idx.data(), idx.size() * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_scatter_set, dim3((idx.size() + 255) / 256), dim3(256), 0, h->stream, d_map, h->d_idxstage, static_cast<uint32_t>(idx.size()), value);
+  KLAUNCH(h, k_scatter_set, dim3((idx.size() + 255) / 256), dim3(256), d_map, h->d_idxstage, static_cast<uint32_t>(idx.size()), value);
   HIPCHK(hipStreamSynchronize(h->stream));
   return VOFOD_OK;
 }
 
 int fill_map(vofod_handle* h, float* p, float v)
 {
-  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, h->stream, p, h->mg.n, v);
+  KLAUNCH(h, k_fill, dim3(2048), dim3(256), p, h->mg.n, v);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -497,18 +538,17 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_
 {
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
-  hipLaunchKernelGGL(k_init_hdr, dim3(n), dim3(64), 0, h->stream, ws.d_hdrs);
-  hipLaunchKernelGGL(k_bbox, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs);
-  hipLaunchKernelGGL(k_grid, dim3(n), dim3(64), 0, h->stream, g, ws.d_hdrs);
+  KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs);
+  KLAUNCH(h, k_bbox, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs);
+  KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
   HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
-  hipLaunchKernelGGL(k_setbits, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
-  hipLaunchKernelGGL(k_scan_a, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
-  hipLaunchKernelGGL(k_scan_b, dim3(n), dim3(1024), 0, h->stream, g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  hipLaunchKernelGGL(k_emit, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
-  hipLaunchKernelGGL(k_count, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr,
-                     ws.pt_cap);
+  KLAUNCH(h, k_setbits, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
+  KLAUNCH(h, k_scan_a, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+  KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
+  KLAUNCH(h, k_emit, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
+  KLAUNCH(h, k_count, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -517,12 +557,11 @@ int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, ui
 {
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
-  hipLaunchKernelGGL(k_setbits, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
-  hipLaunchKernelGGL(k_scan_a, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
-  hipLaunchKernelGGL(k_scan_b, dim3(n), dim3(1024), 0, h->stream, g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  hipLaunchKernelGGL(k_emit, dim3(ws.nblk_cap, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
-  hipLaunchKernelGGL(k_count, dim3(gx, n), dim3(256), 0, h->stream, ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr,
-                     ws.pt_cap);
+  KLAUNCH(h, k_setbits, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
+  KLAUNCH(h, k_scan_a, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+  KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
+  KLAUNCH(h, k_emit, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
+  KLAUNCH(h, k_count, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -541,8 +580,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
   HIPCHK(hipMemcpyAsync(h->d_rows, rows.data(), sizeof(StencilRow) * rows.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));  // rows is a local
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
-  hipLaunchKernelGGL(k_union, dim3(gv, n), dim3(256), 0, h->stream, g, cp, h->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
-  hipLaunchKernelGGL(k_flatten, dim3(gv, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.va, ws.d_labels);
+  KLAUNCH(h, k_union, dim3(gv, n), dim3(256), g, cp, h->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
+  KLAUNCH(h, k_flatten, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -553,7 +592,7 @@ int ensure_mapbits(vofod_handle* h, float thr)
   if (h->mapbits_valid && h->mapbits_thr == thr)
     return VOFOD_OK;
   HIPCHK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
-  hipLaunchKernelGGL(k_mapbits, dim3(256 * 8), dim3(256), 0, h->stream, h->d_map, h->mg.n, thr, h->d_mapbits, h->d_counter);
+  KLAUNCH(h, k_mapbits, dim3(256 * 8), dim3(256), h->d_map, h->mg.n, thr, h->d_mapbits, h->d_counter);
   HIPCHK(hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   h->mapbits_valid = true;
   h->mapbits_thr = thr;
@@ -653,7 +692,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   HIPCHK(hipStreamSynchronize(h->stream));
   CloseParams cpar{static_cast<int>(crows.size()), thr_new};
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
-  hipLaunchKernelGGL(k_closefar, dim3(gv, n), dim3(256), 0, h->stream, g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
+  KLAUNCH(h, k_closefar, dim3(gv, n), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
   if (dbg)
     HIPCHK(hipEventRecord(ev[3], h->stream));
 
@@ -664,8 +703,8 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   up.min_points = dp.classification__min_points;
   up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
   up.no_update = no_update;
-  hipLaunchKernelGGL(k_finalize, dim3(gv, n), dim3(256), 0, h->stream, g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand);
-  hipLaunchKernelGGL(k_pack, dim3((std::max(SPEC_C, SPEC_M) + 255) / 256, n), dim3(256), 0, h->stream, g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
+  KLAUNCH(h, k_finalize, dim3(gv, n), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand);
+  KLAUNCH(h, k_pack, dim3((std::max(SPEC_C, SPEC_M) + 255) / 256, n), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
   HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
   if (dbg)
     HIPCHK(hipEventRecord(ev[4], h->stream));
@@ -724,7 +763,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       h->h_members_big.resize(hdr.n_cand);
       CandMemberX* d_tmp = nullptr;
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_tmp), sizeof(CandMemberX) * hdr.n_cand));
-      hipLaunchKernelGGL(k_gather_members, dim3((hdr.n_cand + 255) / 256), dim3(256), 0, h->stream, g, f, hdr.n_cand, ws.d_cand, ws.va, d_tmp);
+      KLAUNCH(h, k_gather_members, dim3((hdr.n_cand + 255) / 256), dim3(256), g, f, hdr.n_cand, ws.d_cand, ws.va, d_tmp);
       HIPCHK(hipMemcpyAsync(h->h_members_big.data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       (void)hipFree(d_tmp);
