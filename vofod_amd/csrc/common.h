@@ -43,6 +43,7 @@ struct FrameHdr
   uint32_t C;       // clusters
   uint32_t n_cand;  // voxels of candidate (far, small) clusters appended to the member list
   uint32_t need_words;  // bitmap words the lattice needs (reported even when it exceeds the workspace)
+  uint32_t n_bricks;    // occupied 4x4x4 bricks (brick-level clustering)
 };
 
 // Parameters constant over a call (passed by value).

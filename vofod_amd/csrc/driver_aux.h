@@ -210,9 +210,11 @@ int voxelize_cloud(vofod_handle* h, Workspace& ws, const vofod_cloud_view* in, G
     HIPCHK(hipMemcpyAsync(&ws.h_packed[0].hdr, ws.d_hdrs, sizeof(FrameHdr), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     hdr = ws.h_packed[0].hdr;
-    if (hdr.status == VOFOD_ERR_CAPACITY && attempt == 0)
+    const uint32_t need_bricks =
+        hdr.n_in ? static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>((hdr.div_b[0] + 3) / 4) * ((hdr.div_b[1] + 3) / 4) * ((hdr.div_b[2] + 3) / 4), 1u << 28)) : 0u;
+    if ((hdr.status == VOFOD_ERR_CAPACITY || (hdr.status == VOFOD_OK && need_bricks > ws.bricks_cap)) && attempt == 0)
     {
-      if (hipError_t e = ws.ensure(1, n, n, hdr.need_words + 64); e != hipSuccess)
+      if (hipError_t e = ws.ensure(1, n, n, hdr.need_words + 64, need_bricks); e != hipSuccess)
       {
         h->err = std::string("workspace allocation: ") + hipGetErrorString(e);
         return VOFOD_ERR_DEVICE;
@@ -479,6 +481,10 @@ void vofod_destroy(vofod_handle* h)
   for (void* p : ptrs)
     if (p)
       (void)hipFree(p);
+  for (auto& c : h->ctab)
+    for (void* p : {static_cast<void*>(c.d_rows), static_cast<void*>(c.d_boffs), static_cast<void*>(c.d_sure), static_cast<void*>(c.d_amb)})
+      if (p)
+        (void)hipFree(p);
   if (h->h_counter)
     (void)hipHostFree(h->h_counter);
   if (h->sep.h_small)
@@ -578,7 +584,8 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
     return fail(VOFOD_ERR_INDEX_OVERFLOW);
   }
   const uint32_t F = static_cast<uint32_t>(std::max(sp->max_batch_frames, 1));
-  CREATE_CHK(h->ws.ensure(F, static_cast<uint32_t>(n), static_cast<uint32_t>(n), static_cast<uint32_t>((cells + 63) / 64)));
+  const uint32_t nbricks = static_cast<uint32_t>(((sizes[0] + 2 + 3) / 4) * ((sizes[1] + 2 + 3) / 4) * static_cast<uint64_t>((sizes[2] + 2 + 3) / 4));
+  CREATE_CHK(h->ws.ensure(F, static_cast<uint32_t>(n), static_cast<uint32_t>(n), static_cast<uint32_t>((cells + 63) / 64), nbricks));
 #undef CREATE_CHK
   if (do_reset(h) != VOFOD_OK)
     return fail(VOFOD_ERR_DEVICE);
@@ -848,7 +855,8 @@ int vofod_cluster(vofod_handle* h, const vofod_point_xyzr* pts, const uint32_t* 
     }
   Workspace& ws = h->aux;
   const uint32_t words = static_cast<uint32_t>((cells + 63) / 64);
-  if (hipError_t e = ws.ensure(1, static_cast<uint32_t>(n), static_cast<uint32_t>(n), words + 64); e != hipSuccess)
+  const uint32_t need_bricks = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>((grid->div_b[0] + 3) / 4) * ((grid->div_b[1] + 3) / 4) * ((grid->div_b[2] + 3) / 4), 1u << 28));
+  if (hipError_t e = ws.ensure(1, static_cast<uint32_t>(n), static_cast<uint32_t>(n), words + 64, need_bricks); e != hipSuccess)
   {
     h->err = std::string("workspace allocation: ") + hipGetErrorString(e);
     return VOFOD_ERR_DEVICE;

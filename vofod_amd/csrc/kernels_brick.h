@@ -1,0 +1,213 @@
+// Brick-level Euclidean clustering for gfx950 (fast path of K7).
+//
+// When the tolerance is large against the voxel pitch (every pair of voxels inside a 4x4x4 brick is
+// closer than the tolerance: tol/leaf > 3*sqrt(3)), a brick is a clique of the Euclidean graph and can
+// be merged as ONE node.  A brick's occupancy is exactly one 64-bit word (bit = x + 4y + 16z inside the
+// brick), so the neighbourhood test between two bricks is a handful of AND operations against host-built
+// masks: sure[o][p] = the bits q of the neighbour brick at brick offset o that are certainly within the
+// tolerance of bit p, amb[o][p] = the bits sitting on the tolerance boundary, decided by the float
+// expression FLANN evaluates on the actual voxel centres.  The union-find then runs over the
+// few thousand occupied bricks of a frame instead of its tens of thousands of voxels, and a voxel's label
+// is the smallest voxel rank of its brick component (the same canonical label as the voxel-level kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_cluster.h"
+
+namespace vk
+{
+
+struct BrickOff
+{
+  int8_t dx, dy, dz;
+  uint8_t has_amb;
+};
+
+struct BrickParams
+{
+  int32_t n_off;
+  float r2;
+  uint32_t bricks_cap;
+};
+
+struct BrickArrays
+{
+  unsigned long long* bricks;  // occupancy words, all-zero outside a call (cleaned after use)
+  uint32_t* bparent;
+  uint32_t* bmin;   // per brick root: smallest voxel rank of the component
+  uint32_t* blist;  // occupied bricks of the frame (unordered), hdr.n_bricks entries
+};
+
+__device__ __forceinline__ BrickArrays frame_bricks(const BrickArrays& base, uint32_t frame, uint32_t bricks_cap, uint32_t vox_cap)
+{
+  BrickArrays b;
+  b.bricks = base.bricks + static_cast<size_t>(frame) * bricks_cap;
+  b.bparent = base.bparent + static_cast<size_t>(frame) * bricks_cap;
+  b.bmin = base.bmin + static_cast<size_t>(frame) * bricks_cap;
+  b.blist = base.blist + static_cast<size_t>(frame) * vox_cap;
+  return b;
+}
+
+__device__ __forceinline__ void key_to_ijk(const FrameHdr& h, uint32_t key, int& i, int& j, int& k)
+{
+  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+  k = key / dxy;
+  const int rem = key - k * dxy;
+  j = rem / dx;
+  i = rem - j * dx;
+}
+
+__device__ __forceinline__ uint32_t brick_of(const FrameHdr& h, int i, int j, int k, int& bit)
+{
+  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
+  bit = (i & 3) | ((j & 3) << 2) | ((k & 3) << 4);
+  return static_cast<uint32_t>(((k >> 2) * nby + (j >> 2)) * nbx + (i >> 2));
+}
+
+// mark every voxel in its brick word; the first voxel of a brick registers it
+__global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const BrickParams bp, FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all)
+{
+  FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= h.V)
+    return;
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  int i, j, k, bit;
+  key_to_ijk(h, va.key[v], i, j, k);
+  const uint32_t b = brick_of(h, i, j, k, bit);
+  const unsigned long long old = atomicOr(&ba.bricks[b], 1ull << bit);
+  if (old == 0ull)
+  {
+    const uint32_t slot = atomicAdd(&h.n_bricks, 1u);
+    ba.blist[slot] = b;
+    ba.bparent[b] = b;
+    ba.bmin[b] = 0xffffffffu;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const BrickParams bp, const BrickOff* __restrict__ offs,
+                                                     const unsigned long long* __restrict__ sure, const unsigned long long* __restrict__ amb, const FrameHdr* hdrs,
+                                                     BrickArrays ba_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= h.n_bricks)
+    return;
+  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2, nbz = (h.div_b[2] + 3) >> 2;
+  const uint32_t b = ba.blist[t];
+  const unsigned long long A = ba.bricks[b];
+  const int bz = b / (nbx * nby);
+  const int brem = b - bz * nbx * nby;
+  const int by = brem / nbx;
+  const int bx = brem - by * nbx;
+  uint32_t rv = b;  // current representative of this brick's component (refreshed lazily)
+  for (int o = 0; o < bp.n_off; o++)
+  {
+    const BrickOff off = offs[o];
+    const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
+    if (nx < 0 || nx >= nbx || ny < 0 || ny >= nby || nz >= nbz)
+      continue;
+    const uint32_t nb = static_cast<uint32_t>((nz * nby + ny) * nbx + nx);
+    const unsigned long long B = ba.bricks[nb];
+    if (!B)
+      continue;
+    bool conn = false;
+    const unsigned long long* s = sure + static_cast<size_t>(o) * 64;
+    unsigned long long a = A;
+    while (a && !conn)
+    {
+      const int p = __ffsll(static_cast<long long>(a)) - 1;
+      a &= a - 1;
+      conn = (s[p] & B) != 0ull;
+    }
+    if (!conn && off.has_amb)
+    {
+      const unsigned long long* m = amb + static_cast<size_t>(o) * 64;
+      a = A;
+      while (a && !conn)
+      {
+        const int p = __ffsll(static_cast<long long>(a)) - 1;
+        a &= a - 1;
+        unsigned long long cand = m[p] & B;
+        if (!cand)
+          continue;
+        const float px = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+        const float py = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+        const float pz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+        while (cand && !conn)
+        {
+          const int q = __ffsll(static_cast<long long>(cand)) - 1;
+          cand &= cand - 1;
+          const float qx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nx + (q & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+          const float qy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * ny + ((q >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+          const float qz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nz + (q >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+          const float ddx = __fsub_rn(px, qx), ddy = __fsub_rn(py, qy), ddz = __fsub_rn(pz, qz);
+          float d2 = __fmul_rn(ddx, ddx);
+          d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
+          d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
+          conn = d2 < bp.r2;
+        }
+      }
+    }
+    if (conn)
+    {
+      // union(b, nb) with the representative of b kept in a register
+      uint32_t ra = uf_find<2>(ba.bparent, rv), rb = uf_find<2>(ba.bparent, nb);
+      while (ra != rb)
+      {
+        if (ra < rb)
+        {
+          const uint32_t tmp = ra;
+          ra = rb;
+          rb = tmp;
+        }
+        const uint32_t old = atomicCAS(&ba.bparent[ra], ra, rb);
+        if (old == ra)
+          break;
+        ra = old;
+      }
+      rv = min(ra, rb);
+    }
+  }
+}
+
+// per voxel: representative brick of its component (stored in labels[]), smallest voxel rank per component
+__global__ __launch_bounds__(256) void k_brick_min(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all,
+                                                   uint32_t* labels_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = v < h.V;
+  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  uint32_t R = 0xffffffffu;
+  if (active)
+  {
+    int i, j, k, bit;
+    key_to_ijk(h, va.key[v], i, j, k);
+    R = brick_of(h, i, j, k, bit);
+    uint32_t p;
+    while ((p = ba.bparent[R]) != R)
+      R = p;
+    labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v] = R;
+  }
+  // consecutive voxels mostly share the component: one atomicMin per run of equal roots inside the wave
+  const uint32_t prevR = __shfl_up(R, 1);
+  const bool head = active && ((threadIdx.x & 63) == 0 || prevR != R);
+  if (head)
+    atomicMin(&ba.bmin[R], v);  // lanes are in ascending v, so the head of a run holds its minimum
+}
+
+__global__ __launch_bounds__(256) void k_brick_clear(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, BrickArrays ba_all)
+{
+  const FrameHdr& h = hdrs[blockIdx.y];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= h.n_bricks)
+    return;
+  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  ba.bricks[ba.blist[t]] = 0ull;
+}
+
+}  // namespace vk

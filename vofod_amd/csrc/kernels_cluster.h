@@ -17,19 +17,35 @@
 namespace vk
 {
 
-__device__ __forceinline__ uint32_t uf_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void uf_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// MODE 0: agent-scope relaxed loads (L2-served) and stores; 1: agent loads, no path compression;
+//      2: plain loads/stores (L1-cached; stale parents are ancestors, the hooking CAS stays coherent)
+template <int MODE>
+__device__ __forceinline__ uint32_t uf_ld(const uint32_t* p)
+{
+  if (MODE == 2)
+    return *reinterpret_cast<const volatile uint32_t*>(p);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int MODE>
+__device__ __forceinline__ void uf_st(uint32_t* p, uint32_t v)
+{
+  if (MODE == 0)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (MODE == 2)
+    *reinterpret_cast<volatile uint32_t*>(p) = v;
+}
 
 // representative with intermediate pointer jumping (parents only ever decrease)
+template <int MODE>
 __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t v)
 {
-  uint32_t curr = uf_ld(&parent[v]);
+  uint32_t curr = uf_ld<MODE>(&parent[v]);
   if (curr != v)
   {
     uint32_t prev = v, next;
-    while (curr > (next = uf_ld(&parent[curr])))
+    while (curr > (next = uf_ld<MODE>(&parent[curr])))
     {
-      uf_st(&parent[prev], next);
+      uf_st<MODE>(&parent[prev], next);
       prev = curr;
       curr = next;
     }
@@ -37,9 +53,10 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t v)
   return curr;
 }
 
+template <int MODE>
 __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b)
 {
-  uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
+  uint32_t ra = uf_find<MODE>(parent, a), rb = uf_find<MODE>(parent, b);
   while (ra != rb)
   {
     if (ra < rb)
@@ -56,6 +73,7 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
   }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void k_union(const GridParams g, const ClusterParams cp, const StencilRow* __restrict__ rows, const FrameHdr* hdrs,
                                                const unsigned long long* bitmaps, const uint32_t* wprefix_all, VoxelArrays va_all)
 {
@@ -73,7 +91,23 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
   const int j = rem / dx;
   const int i = rem - j * dx;
   float4 pv = va.pts[v];
-  const unsigned long long gapmask = cp.row_gap >= 0 ? ((2ull << cp.row_gap) - 1ull) : 1ull;
+  const unsigned long long gapmask = (2ull << cp.row_gap) - 1ull;
+
+  // Distance d to the previous occupied cell of the own row if it lies within the sure in-row gap (0: none).
+  // That voxel is in v's component for certain (its own-row pass links it to v) and has already examined
+  // every cell of a neighbour row up to x = i - d + r_sure, so v only has to look at the d cells beyond.
+  int d = 0;
+  if (cp.row_gap > 0 && i > 0)
+  {
+    const int back = min(cp.row_gap, i);
+    const uint32_t L = key - back;
+    const uint32_t wi = L >> 6;
+    const int sh = L & 63;
+    unsigned long long win = (bm[wi] >> sh) | (sh ? (bm[wi + 1] << (64 - sh)) : 0ull);
+    win &= (1ull << back) - 1ull;
+    if (win)
+      d = back - (63 - __clzll(static_cast<long long>(win)));
+  }
 
   for (int r = 0; r < cp.n_rows; r++)
   {
@@ -82,7 +116,11 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
     if (jj < 0 || jj >= dy || kk >= dz)
       continue;
     const bool own_row = (row.dj == 0 && row.dk == 0);
-    const int lo = own_row ? i + 1 : max(i - row.r_max, 0);
+    // cells [i - r_sure, covered] of this row were handled by the previous voxel of the own row
+    const int covered = (d > 0 && !own_row) ? i - d + row.r_sure : -0x40000000;
+    int lo = own_row ? i + 1 : max(i - row.r_max, 0);
+    if (!own_row && d > 0 && row.amb == 0u)
+      lo = max(lo, covered + 1);
     const int hi = min(i + row.r_max, dx - 1);
     if (lo > hi)
       continue;
@@ -91,8 +129,9 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
     const uint32_t wi = L >> 6;
     const int sh = L & 63;
     const unsigned long long w0 = bm[wi];
-    const unsigned long long w1 = bm[wi + 1];  // guard words are allocated past n_words
-    unsigned long long win = (w0 >> sh) | (sh ? (w1 << (64 - sh)) : 0ull);
+    unsigned long long win = w0 >> sh;
+    if (sh + nbits > 64)
+      win |= bm[wi + 1] << (64 - sh);  // guard words are allocated past n_words
     win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
     if (!win)
       continue;
@@ -101,9 +140,15 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
     while (win)
     {
       const int t = __ffsll(static_cast<long long>(win)) - 1;
-      const int adi = abs(lo + t - i);
-      const uint32_t nb = pre + __popcll(win0 & ((1ull << t) - 1ull));
+      const int pos = lo + t;
+      const int adi = abs(pos - i);
       bool ok = adi <= row.r_sure;
+      if (ok && pos <= covered)
+      {
+        win &= win - 1;  // already linked through the previous voxel of the own row
+        continue;
+      }
+      const uint32_t nb = pre + __popcll(win0 & ((1ull << t) - 1ull));
       if (!ok && ((row.amb >> adi) & 1u))
       {
         const float4 pn = va.pts[nb];
@@ -115,8 +160,8 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
       }
       if (ok)
       {
-        uf_union(va.parent, v, nb);
-        // bits within the sure in-row gap of this neighbour are linked to it by their own row-(0,0) pass
+        uf_union<MODE>(va.parent, v, nb);
+        // cells within the sure in-row gap of this neighbour are linked to it by their own row-(0,0) pass
         win &= ~(gapmask << t);
       }
       else
@@ -126,8 +171,27 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
 }
 
 // Flatten the forest (label = root = smallest member) and accumulate per-cluster size and lattice AABB.
-__global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all)
+// Cluster statistics are pre-aggregated per wave (shuffles) and per block (a small LDS hash keyed by root)
+// so that the one giant ground cluster does not serialise thousands of global atomics on seven addresses.
+constexpr int FL_SLOTS = 64;
+template <int SRC>
+__global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all, const uint32_t* bmin_all,
+                                                 uint32_t bricks_cap)
 {
+  __shared__ uint32_t s_root[FL_SLOTS];
+  __shared__ uint32_t s_cnt[FL_SLOTS];
+  __shared__ int s_box[FL_SLOTS][6];
+  for (int t = threadIdx.x; t < FL_SLOTS; t += blockDim.x)
+  {
+    s_root[t] = 0xffffffffu;
+    s_cnt[t] = 0;
+    for (int c = 0; c < 3; c++)
+    {
+      s_box[t][c] = 0x7fffffff;
+      s_box[t][3 + c] = static_cast<int>(0x80000000u);
+    }
+  }
+  __syncthreads();
   const FrameHdr& h = hdrs[blockIdx.y];
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = v < h.V;
@@ -137,10 +201,15 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
   int ijk[3] = {0, 0, 0};
   if (active)
   {
-    root = v;
-    uint32_t p;
-    while ((p = va.parent[root]) != root)
-      root = p;
+    if (SRC == 0)
+    {
+      root = v;
+      uint32_t p;
+      while ((p = va.parent[root]) != root)
+        root = p;
+    }
+    else
+      root = bmin_all[static_cast<size_t>(blockIdx.y) * bricks_cap + labels[v]];
     labels[v] = root;
     const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
     const uint32_t key = va.key[v];
@@ -149,48 +218,82 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
     ijk[1] = rem / dx;
     ijk[0] = rem - ijk[1] * dx;
   }
-  // wave aggregation: on surfaces nearly every lane of a wave belongs to the same (ground) cluster,
-  // so the wave's leading cluster is reduced with shuffles and committed by one lane.
+  // wave level: reduce the wave's leading cluster with shuffles
   const unsigned long long m_active = __ballot(active);
-  if (m_active == 0)
-    return;
-  const int lead_lane = __ffsll(static_cast<long long>(m_active)) - 1;
-  const uint32_t lead = __shfl(root, lead_lane);
-  const bool same = active && root == lead;
-  const uint32_t n_same = __popcll(__ballot(same));
-  int mn[3], mx[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++)
+  uint32_t lead = 0xffffffffu;
+  bool same = false;
+  uint32_t n_same = 0;
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
+  int lead_lane = -1;
+  if (m_active)
   {
-    mn[c] = same ? ijk[c] : 0x7fffffff;
-    mx[c] = same ? ijk[c] : static_cast<int>(0x80000000u);
-  }
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1)
+    lead_lane = __ffsll(static_cast<long long>(m_active)) - 1;
+    lead = __shfl(root, lead_lane);
+    same = active && root == lead;
+    n_same = __popcll(__ballot(same));
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
-      mn[c] = min(mn[c], __shfl_xor(mn[c], s));
-      mx[c] = max(mx[c], __shfl_xor(mx[c], s));
+      mn[c] = same ? ijk[c] : 0x7fffffff;
+      mx[c] = same ? ijk[c] : static_cast<int>(0x80000000u);
     }
-  if (static_cast<int>(threadIdx.x & 63) == lead_lane)
-  {
-    atomicAdd(&va.csize[lead], n_same);
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+    for (int s = 32; s > 0; s >>= 1)
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        mn[c] = min(mn[c], __shfl_xor(mn[c], s));
+        mx[c] = max(mx[c], __shfl_xor(mx[c], s));
+      }
+  }
+  // block level: one contribution per (wave, leading root) plus the stragglers go through the LDS hash
+  const bool is_lead = m_active && static_cast<int>(threadIdx.x & 63) == lead_lane;
+  const bool straggler = active && !same;
+  if (is_lead || straggler)
+  {
+    const uint32_t rt = is_lead ? lead : root;
+    const uint32_t cnt = is_lead ? n_same : 1u;
+    int slot = (rt * 2654435761u) >> 26;  // 64 slots
+    bool done = false;
+    for (int probe = 0; probe < FL_SLOTS && !done; probe++)
     {
-      atomicMin(&va.cbox[6 * lead + c], mn[c]);
-      atomicMax(&va.cbox[6 * lead + 3 + c], mx[c]);
+      const uint32_t old = atomicCAS(&s_root[slot], 0xffffffffu, rt);
+      if (old == 0xffffffffu || old == rt)
+      {
+        atomicAdd(&s_cnt[slot], cnt);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+        {
+          atomicMin(&s_box[slot][c], is_lead ? mn[c] : ijk[c]);
+          atomicMax(&s_box[slot][3 + c], is_lead ? mx[c] : ijk[c]);
+        }
+        done = true;
+      }
+      slot = (slot + 1) & (FL_SLOTS - 1);
+    }
+    if (!done)  // hash full (more than 64 distinct clusters in one block): go to global memory directly
+    {
+      atomicAdd(&va.csize[rt], cnt);
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        atomicMin(&va.cbox[6 * rt + c], is_lead ? mn[c] : ijk[c]);
+        atomicMax(&va.cbox[6 * rt + 3 + c], is_lead ? mx[c] : ijk[c]);
+      }
     }
   }
-  if (active && !same)
+  __syncthreads();
+  for (int t = threadIdx.x; t < FL_SLOTS; t += blockDim.x)
   {
-    atomicAdd(&va.csize[root], 1u);
+    const uint32_t rt = s_root[t];
+    if (rt == 0xffffffffu)
+      continue;
+    atomicAdd(&va.csize[rt], s_cnt[t]);
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
-      atomicMin(&va.cbox[6 * root + c], ijk[c]);
-      atomicMax(&va.cbox[6 * root + 3 + c], ijk[c]);
+      atomicMin(&va.cbox[6 * rt + c], s_box[t][c]);
+      atomicMax(&va.cbox[6 * rt + 3 + c], s_box[t][3 + c]);
     }
   }
 }

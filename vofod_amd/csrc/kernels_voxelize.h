@@ -82,6 +82,7 @@ __global__ void k_init_hdr(FrameHdr* hdrs)
     h.n_cells = h.n_words = 0;
     h.V = h.C = h.n_cand = 0;
     h.need_words = 0;
+    h.n_bricks = 0;
   }
 }
 
@@ -117,15 +118,41 @@ __global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridP
       mx[c] = max(mx[c], __shfl_xor(mx[c], s));
     }
   }
-  if ((threadIdx.x & 63) == 0 && cnt)
+  // block-level combine in LDS, then one set of atomics per block
+  __shared__ int s_red[4][7];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
   {
-    FrameHdr& h = hdrs[blockIdx.y];
-    atomicAdd(&h.n_in, cnt);
-#pragma unroll
+    s_red[wave][0] = static_cast<int>(cnt);
     for (int c = 0; c < 3; c++)
     {
-      atomicMin(&h.bb_min[c], mn[c]);
-      atomicMax(&h.bb_max[c], mx[c]);
+      s_red[wave][1 + c] = mn[c];
+      s_red[wave][4 + c] = mx[c];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t tot = 0;
+    for (int w = 0; w < 4; w++)
+    {
+      tot += static_cast<uint32_t>(s_red[w][0]);
+      for (int c = 0; c < 3; c++)
+      {
+        mn[c] = min(mn[c], s_red[w][1 + c]);
+        mx[c] = max(mx[c], s_red[w][4 + c]);
+      }
+    }
+    if (tot)
+    {
+      FrameHdr& h = hdrs[blockIdx.y];
+      atomicAdd(&h.n_in, tot);
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        atomicMin(&h.bb_min[c], mn[c]);
+        atomicMax(&h.bb_max[c], mx[c]);
+      }
     }
   }
 }

@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "host_tail.h"
+#include "kernels_brick.h"
 #include "kernels_cluster.h"
 #include "kernels_raycast.h"
 #include "kernels_voxelize.h"
@@ -151,7 +152,8 @@ struct Prof
 
 struct Workspace
 {
-  uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0;
+  uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0, bricks_cap = 0;
+  BrickArrays ba{};
   FrameArgs* d_args = nullptr;
   FrameHdr* d_hdrs = nullptr;
   unsigned long long* d_bitmaps = nullptr;
@@ -169,7 +171,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
+    void* ptrs[] = {ba.bricks, ba.bparent, ba.bmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -178,25 +180,33 @@ struct Workspace
     *this = Workspace();
   }
 
-  hipError_t ensure(uint32_t F_, uint32_t pt_cap_, uint32_t vox_cap_, uint32_t words_cap_)
+  hipError_t ensure(uint32_t F_, uint32_t pt_cap_, uint32_t vox_cap_, uint32_t words_cap_, uint32_t bricks_cap_ = 0)
   {
-    if (F_ <= F && pt_cap_ <= pt_cap && vox_cap_ <= vox_cap && words_cap_ <= words_cap)
+    if (F_ <= F && pt_cap_ <= pt_cap && vox_cap_ <= vox_cap && words_cap_ <= words_cap && bricks_cap_ <= bricks_cap)
       return hipSuccess;
     F_ = std::max(F_, F);
     pt_cap_ = std::max(pt_cap_, pt_cap);
     vox_cap_ = std::max(vox_cap_, vox_cap);
     words_cap_ = std::max(words_cap_, words_cap);
+    bricks_cap_ = std::max(bricks_cap_, bricks_cap);
     release();
     F = F_;
     pt_cap = pt_cap_;
     vox_cap = vox_cap_;
     words_cap = words_cap_;
+    bricks_cap = bricks_cap_;
     nblk_cap = (words_cap + SCAN_WPB - 1) / SCAN_WPB + 1;
     hipError_t e;
     const size_t FV = static_cast<size_t>(F) * vox_cap;
 #define WS_ALLOC(ptr, bytes)                                     \
   if ((e = hipMalloc(reinterpret_cast<void**>(&ptr), (bytes))) != hipSuccess) \
     return e;
+    WS_ALLOC(ba.bricks, sizeof(unsigned long long) * F * std::max<size_t>(bricks_cap, 1));
+    if ((e = hipMemset(ba.bricks, 0, sizeof(unsigned long long) * F * std::max<size_t>(bricks_cap, 1))) != hipSuccess)
+      return e;
+    WS_ALLOC(ba.bparent, sizeof(uint32_t) * F * std::max<size_t>(bricks_cap, 1));
+    WS_ALLOC(ba.bmin, sizeof(uint32_t) * F * std::max<size_t>(bricks_cap, 1));
+    WS_ALLOC(ba.blist, sizeof(uint32_t) * FV);
     WS_ALLOC(d_args, sizeof(FrameArgs) * F);
     WS_ALLOC(d_hdrs, sizeof(FrameHdr) * F);
     WS_ALLOC(d_bitmaps, sizeof(unsigned long long) * F * (static_cast<size_t>(words_cap) + 2));
@@ -258,6 +268,25 @@ struct vofod_handle
   uint8_t* d_mask = nullptr;
 
   Workspace ws, aux, sepws;
+  struct ClusterTables
+  {
+    bool valid = false;
+    float leaf[3] = {0, 0, 0}, tol = 0, cmax = 0;
+    ClusterParams cp{};
+    int n_rows = 0;
+    StencilRow* d_rows = nullptr;
+    bool brick_ok = false;
+    BrickParams bp{};
+    BrickOff* d_boffs = nullptr;
+    unsigned long long *d_sure = nullptr, *d_amb = nullptr;
+  } ctab[2];
+  int ctab_next = 0;
+  struct CloseTables
+  {
+    bool valid = false;
+    float max_dist = 0;
+    int n_rows = 0;
+  } closetab;
   bool ray_dirty = false;
   StencilRow* d_rows = nullptr;
   CloseRow* d_crows = nullptr;
@@ -282,24 +311,24 @@ namespace
 
 // ------------------------------------------------------------------ tables built on the host
 
-// Half stencil of the Euclidean predicate d2 < tol^2 on a lattice of pitch `leaf` whose centre
-// coordinates are bounded by cmax in magnitude.  An offset is "sure" when its nominal squared distance
-// differs from tol^2 by more than the worst float evaluation error, "ambiguous" otherwise.
-int build_cluster_stencil(const float leaf[3], float tol, float cmax, std::vector<StencilRow>& rows, ClusterParams& cp)
+// Decides, for a lattice offset (di,dj,dk), whether two voxel centres that far apart are within the tolerance:
+// 1 certainly (nominal squared distance below tol^2 by more than the worst float evaluation error),
+// 0 certainly not, 2 on the boundary -> the kernels evaluate FLANN's float expression on the actual centres.
+struct EdgeClassifier
 {
-  rows.clear();
-  const float r2f = tol * tol;
-  const double r2 = r2f;
-  int R[3];
-  for (int a = 0; a < 3; a++)
+  double leaf[3], r2, delta;
+  float r2f;
+  EdgeClassifier(const float leaf_[3], float tol, float cmax)
   {
-    R[a] = static_cast<int>(std::ceil(static_cast<double>(tol) / leaf[a])) + 1;
-    if (R[a] > MAX_R)
-      return VOFOD_ERR_INVALID_ARG;
+    r2f = tol * tol;
+    r2 = r2f;
+    for (int a = 0; a < 3; a++)
+      leaf[a] = leaf_[a];
+    delta = 2.0 * ulp32(cmax);  // error bound of one centre coordinate (two roundings)
   }
-  const double delta = 2.0 * ulp32(cmax);  // error bound of one centre coordinate (two roundings)
-  auto classify = [&](int di, int dj, int dk) -> int {  // 1 sure-in, 0 sure-out, 2 ambiguous
-    const double ex = std::fabs(di) * static_cast<double>(leaf[0]), ey = std::fabs(dj) * static_cast<double>(leaf[1]), ez = std::fabs(dk) * static_cast<double>(leaf[2]);
+  int operator()(int di, int dj, int dk) const
+  {
+    const double ex = std::abs(di) * leaf[0], ey = std::abs(dj) * leaf[1], ez = std::abs(dk) * leaf[2];
     const double D = ex * ex + ey * ey + ez * ez;
     const double eps = 2.0 * delta + 3.0 * ulp32(static_cast<float>(std::max({ex, ey, ez, 1e-30})));
     const double E = 2.0 * eps * (ex + ey + ez) + 3.0 * eps * eps + 8.0 * D * 1.2e-7;
@@ -308,7 +337,21 @@ int build_cluster_stencil(const float leaf[3], float tol, float cmax, std::vecto
     if (D - E >= r2)
       return 0;
     return 2;
-  };
+  }
+};
+
+// Half stencil of the Euclidean predicate d2 < tol^2 on a lattice of pitch `leaf` (voxel-level kernel).
+int build_cluster_stencil(const float leaf[3], float tol, float cmax, std::vector<StencilRow>& rows, ClusterParams& cp)
+{
+  rows.clear();
+  int R[3];
+  for (int a = 0; a < 3; a++)
+  {
+    R[a] = static_cast<int>(std::ceil(static_cast<double>(tol) / leaf[a])) + 1;
+    if (R[a] > MAX_R)
+      return VOFOD_ERR_INVALID_ARG;
+  }
+  const EdgeClassifier classify(leaf, tol, cmax);
   cp.row_gap = -1;
   for (int dk = 0; dk <= R[2]; dk++)
     for (int dj = (dk == 0 ? 0 : -R[1]); dj <= R[1]; dj++)
@@ -347,10 +390,56 @@ int build_cluster_stencil(const float leaf[3], float tol, float cmax, std::vecto
   if (rows.size() > MAX_STENCIL_ROWS)
     return VOFOD_ERR_INVALID_ARG;
   cp.n_rows = static_cast<int>(rows.size());
-  cp.r2 = r2f;
+  cp.r2 = classify.r2f;
   if (cp.row_gap < 0)
     cp.row_gap = 0;
   return VOFOD_OK;
+}
+
+// Brick-level tables (kernels_brick.h).  Returns false when a 4x4x4 brick is not a clique for this tolerance.
+bool build_brick_tables(const float leaf[3], float tol, float cmax, std::vector<BrickOff>& offs, std::vector<unsigned long long>& sure, std::vector<unsigned long long>& amb)
+{
+  offs.clear();
+  sure.clear();
+  amb.clear();
+  const EdgeClassifier classify(leaf, tol, cmax);
+  if (classify(3, 3, 3) != 1)
+    return false;
+  int Rb[3];
+  for (int a = 0; a < 3; a++)
+  {
+    const int r_max = static_cast<int>(std::ceil(static_cast<double>(tol) / leaf[a])) + 1;
+    Rb[a] = (r_max + 3 + 3) / 4;
+  }
+  for (int bz = 0; bz <= Rb[2]; bz++)
+    for (int by = (bz == 0 ? 0 : -Rb[1]); by <= Rb[1]; by++)
+      for (int bx = ((bz == 0 && by == 0) ? 1 : -Rb[0]); bx <= Rb[0]; bx++)
+      {
+        unsigned long long ms[64], ma[64];
+        bool any = false, any_amb = false;
+        for (int p = 0; p < 64; p++)
+        {
+          ms[p] = ma[p] = 0;
+          const int px = p & 3, py = (p >> 2) & 3, pz = p >> 4;
+          for (int q = 0; q < 64; q++)
+          {
+            const int qx = q & 3, qy = (q >> 2) & 3, qz = q >> 4;
+            const int c = classify(4 * bx + qx - px, 4 * by + qy - py, 4 * bz + qz - pz);
+            if (c == 1)
+              ms[p] |= 1ull << q;
+            else if (c == 2)
+              ma[p] |= 1ull << q;
+          }
+          any |= (ms[p] | ma[p]) != 0;
+          any_amb |= ma[p] != 0;
+        }
+        if (!any)
+          continue;
+        offs.push_back(BrickOff{static_cast<int8_t>(bx), static_cast<int8_t>(by), static_cast<int8_t>(bz), static_cast<uint8_t>(any_amb)});
+        sure.insert(sure.end(), ms, ms + 64);
+        amb.insert(amb.end(), ma, ma + 64);
+      }
+  return true;
 }
 
 // Rows of hasCloseTo's half-open cube (voxel_map.cpp:380-393), nearest rows first.
@@ -539,7 +628,8 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs);
-  KLAUNCH(h, k_bbox, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs);
+  const uint32_t gb = std::max(1u, std::min((max_pts + 2047u) / 2048u, 1024u));  // 8 points per thread: few header atomics
+  KLAUNCH(h, k_bbox, dim3(gb, n), dim3(256), ws.d_args, g, ws.d_hdrs);
   KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
@@ -566,22 +656,75 @@ int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, ui
   return VOFOD_OK;
 }
 
-// K7: union-find CCL over the occupancy bitmap + flatten
+// K7: Euclidean clustering.  Tables are cached per (leaf, tolerance, coordinate bound).
 int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax)
 {
-  std::vector<StencilRow> rows;
-  ClusterParams cp{};
-  const int r = build_cluster_stencil(g.leaf, tol, cmax, rows, cp);
-  if (r != VOFOD_OK)
+  vofod_handle::ClusterTables* ct = nullptr;
+  for (auto& c : h->ctab)
+    if (c.valid && c.tol == tol && c.cmax == cmax && c.leaf[0] == g.leaf[0] && c.leaf[1] == g.leaf[1] && c.leaf[2] == g.leaf[2])
+      ct = &c;
+  if (!ct)
   {
-    h->err = "cluster tolerance / leaf ratio exceeds the 63-bit neighbour window";
-    return r;
+    ct = &h->ctab[h->ctab_next];
+    h->ctab_next ^= 1;
+    ct->valid = false;
+    std::vector<StencilRow> rows;
+    const int r = build_cluster_stencil(g.leaf, tol, cmax, rows, ct->cp);
+    if (r != VOFOD_OK)
+    {
+      h->err = "cluster tolerance / leaf ratio exceeds the 63-bit neighbour window";
+      return r;
+    }
+    std::vector<BrickOff> offs;
+    std::vector<unsigned long long> sure, amb;
+    ct->brick_ok = build_brick_tables(g.leaf, tol, cmax, offs, sure, amb);
+    for (void* p : {static_cast<void*>(ct->d_rows), static_cast<void*>(ct->d_boffs), static_cast<void*>(ct->d_sure), static_cast<void*>(ct->d_amb)})
+      if (p)
+        (void)hipFree(p);
+    ct->d_rows = nullptr;
+    ct->d_boffs = nullptr;
+    ct->d_sure = ct->d_amb = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_rows), sizeof(StencilRow) * std::max<size_t>(rows.size(), 1)));
+    HIPCHK(hipMemcpy(ct->d_rows, rows.data(), sizeof(StencilRow) * rows.size(), hipMemcpyHostToDevice));
+    ct->n_rows = static_cast<int>(rows.size());
+    if (ct->brick_ok)
+    {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_boffs), sizeof(BrickOff) * std::max<size_t>(offs.size(), 1)));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_sure), sizeof(unsigned long long) * std::max<size_t>(sure.size(), 1)));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_amb), sizeof(unsigned long long) * std::max<size_t>(amb.size(), 1)));
+      HIPCHK(hipMemcpy(ct->d_boffs, offs.data(), sizeof(BrickOff) * offs.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ct->d_sure, sure.data(), sizeof(unsigned long long) * sure.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ct->d_amb, amb.data(), sizeof(unsigned long long) * amb.size(), hipMemcpyHostToDevice));
+      ct->bp.n_off = static_cast<int>(offs.size());
+      ct->bp.r2 = ct->cp.r2;
+    }
+    ct->tol = tol;
+    ct->cmax = cmax;
+    for (int a = 0; a < 3; a++)
+      ct->leaf[a] = g.leaf[a];
+    ct->valid = true;
   }
-  HIPCHK(hipMemcpyAsync(h->d_rows, rows.data(), sizeof(StencilRow) * rows.size(), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));  // rows is a local
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
-  KLAUNCH(h, k_union, dim3(gv, n), dim3(256), g, cp, h->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
-  KLAUNCH(h, k_flatten, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels);
+  // VOFOD_CCL=voxel|brick forces a kernel family (tests compare both against the oracle)
+  static const char* force = std::getenv("VOFOD_CCL");
+  bool use_brick = ct->brick_ok && ws.bricks_cap > 0;
+  if (force && std::strcmp(force, "voxel") == 0)
+    use_brick = false;
+  if (use_brick)
+  {
+    BrickParams bp = ct->bp;
+    bp.bricks_cap = ws.bricks_cap;
+    KLAUNCH(h, k_brick_set, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
+    KLAUNCH(h, k_brick_union, dim3(gv, n), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
+    KLAUNCH(h, k_brick_min, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba, ws.d_labels);
+    KLAUNCH(h, k_flatten<1>, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba.bmin, ws.bricks_cap);
+    KLAUNCH(h, k_brick_clear, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.ba);
+  }
+  else
+  {
+    KLAUNCH(h, k_union<2>, dim3(gv, n), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
+    KLAUNCH(h, k_flatten<0>, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, static_cast<const uint32_t*>(nullptr), 0u);
+  }
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -681,16 +824,21 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   r = ensure_mapbits(h, thr_new);
   if (r != VOFOD_OK)
     return r;
-  std::vector<CloseRow> crows;
-  r = build_close_rows(static_cast<float>(dp.ground_points_max_distance), h->mg.vs_inv, crows);
-  if (r != VOFOD_OK)
+  if (!h->closetab.valid || h->closetab.max_dist != static_cast<float>(dp.ground_points_max_distance))
   {
-    h->err = "ground_points_max_distance / voxel_size exceeds the 63-bit window";
-    return r;
+    std::vector<CloseRow> crows;
+    r = build_close_rows(static_cast<float>(dp.ground_points_max_distance), h->mg.vs_inv, crows);
+    if (r != VOFOD_OK)
+    {
+      h->err = "ground_points_max_distance / voxel_size exceeds the 63-bit window";
+      return r;
+    }
+    HIPCHK(hipMemcpy(h->d_crows, crows.data(), sizeof(CloseRow) * crows.size(), hipMemcpyHostToDevice));
+    h->closetab.valid = true;
+    h->closetab.max_dist = static_cast<float>(dp.ground_points_max_distance);
+    h->closetab.n_rows = static_cast<int>(crows.size());
   }
-  HIPCHK(hipMemcpyAsync(h->d_crows, crows.data(), sizeof(CloseRow) * crows.size(), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  CloseParams cpar{static_cast<int>(crows.size()), thr_new};
+  CloseParams cpar{h->closetab.n_rows, thr_new};
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
   KLAUNCH(h, k_closefar, dim3(gv, n), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
   if (dbg)
