@@ -86,12 +86,15 @@ __global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const Bri
   }
 }
 
+template <int BRICK_LANES>
 __global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const BrickParams bp, const BrickOff* __restrict__ offs,
                                                      const unsigned long long* __restrict__ sure, const unsigned long long* __restrict__ amb, const FrameHdr* hdrs,
                                                      BrickArrays ba_all)
 {
   const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  // BRICK_LANES lanes share one brick and split its neighbour offsets: short dependent chains, 8x the waves
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / BRICK_LANES;
+  const int sub = threadIdx.x % BRICK_LANES;
   if (t >= h.n_bricks)
     return;
   const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
@@ -103,72 +106,95 @@ __global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const B
   const int by = brem / nbx;
   const int bx = brem - by * nbx;
   uint32_t rv = b;  // current representative of this brick's component (refreshed lazily)
-  for (int o = 0; o < bp.n_off; o++)
+  constexpr int CH = 4;  // neighbour words fetched per round: independent loads in flight
+  for (int o0 = sub * CH; o0 < bp.n_off; o0 += CH * BRICK_LANES)
   {
-    const BrickOff off = offs[o];
-    const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
-    if (nx < 0 || nx >= nbx || ny < 0 || ny >= nby || nz >= nbz)
-      continue;
-    const uint32_t nb = static_cast<uint32_t>((nz * nby + ny) * nbx + nx);
-    const unsigned long long B = ba.bricks[nb];
-    if (!B)
-      continue;
-    bool conn = false;
-    const unsigned long long* s = sure + static_cast<size_t>(o) * 64;
-    unsigned long long a = A;
-    while (a && !conn)
+    unsigned long long Bw[CH];
+    uint32_t nbi[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++)
     {
-      const int p = __ffsll(static_cast<long long>(a)) - 1;
-      a &= a - 1;
-      conn = (s[p] & B) != 0ull;
+      Bw[c] = 0ull;
+      nbi[c] = 0;
+      const int o = o0 + c;
+      if (o < bp.n_off)
+      {
+        const BrickOff off = offs[o];
+        const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
+        if (nx >= 0 && nx < nbx && ny >= 0 && ny < nby && nz < nbz)
+        {
+          nbi[c] = static_cast<uint32_t>((nz * nby + ny) * nbx + nx);
+          Bw[c] = ba.bricks[nbi[c]];
+        }
+      }
     }
-    if (!conn && off.has_amb)
+#pragma unroll
+    for (int c = 0; c < CH; c++)
     {
-      const unsigned long long* m = amb + static_cast<size_t>(o) * 64;
-      a = A;
+      const unsigned long long B = Bw[c];
+      if (!B)
+        continue;
+      const int o = o0 + c;
+      const BrickOff off = offs[o];
+      const uint32_t nb = nbi[c];
+      const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
+      bool conn = false;
+      const unsigned long long* s = sure + static_cast<size_t>(o) * 64;
+      unsigned long long a = A;
       while (a && !conn)
       {
         const int p = __ffsll(static_cast<long long>(a)) - 1;
         a &= a - 1;
-        unsigned long long cand = m[p] & B;
-        if (!cand)
-          continue;
-        const float px = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
-        const float py = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
-        const float pz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
-        while (cand && !conn)
-        {
-          const int q = __ffsll(static_cast<long long>(cand)) - 1;
-          cand &= cand - 1;
-          const float qx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nx + (q & 3)), 0.5f), g.leaf[0]), h.offset[0]);
-          const float qy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * ny + ((q >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
-          const float qz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nz + (q >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
-          const float ddx = __fsub_rn(px, qx), ddy = __fsub_rn(py, qy), ddz = __fsub_rn(pz, qz);
-          float d2 = __fmul_rn(ddx, ddx);
-          d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
-          d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
-          conn = d2 < bp.r2;
-        }
+        conn = (s[p] & B) != 0ull;
       }
-    }
-    if (conn)
-    {
-      // union(b, nb) with the representative of b kept in a register
-      uint32_t ra = uf_find<2>(ba.bparent, rv), rb = uf_find<2>(ba.bparent, nb);
-      while (ra != rb)
+      if (!conn && off.has_amb)
       {
-        if (ra < rb)
+        const unsigned long long* m = amb + static_cast<size_t>(o) * 64;
+        a = A;
+        while (a && !conn)
         {
-          const uint32_t tmp = ra;
-          ra = rb;
-          rb = tmp;
+          const int p = __ffsll(static_cast<long long>(a)) - 1;
+          a &= a - 1;
+          unsigned long long cand = m[p] & B;
+          if (!cand)
+            continue;
+          const float px = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+          const float py = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+          const float pz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+          while (cand && !conn)
+          {
+            const int q = __ffsll(static_cast<long long>(cand)) - 1;
+            cand &= cand - 1;
+            const float qx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nx + (q & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+            const float qy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * ny + ((q >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+            const float qz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nz + (q >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+            const float ddx = __fsub_rn(px, qx), ddy = __fsub_rn(py, qy), ddz = __fsub_rn(pz, qz);
+            float d2 = __fmul_rn(ddx, ddx);
+            d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
+            d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
+            conn = d2 < bp.r2;
+          }
         }
-        const uint32_t old = atomicCAS(&ba.bparent[ra], ra, rb);
-        if (old == ra)
-          break;
-        ra = old;
       }
-      rv = min(ra, rb);
+      if (conn)
+      {
+        // union(b, nb) with the representative of b kept in a register
+        uint32_t ra = uf_find<2>(ba.bparent, rv), rb = uf_find<2>(ba.bparent, nb);
+        while (ra != rb)
+        {
+          if (ra < rb)
+          {
+            const uint32_t tmp = ra;
+            ra = rb;
+            rb = tmp;
+          }
+          const uint32_t old = atomicCAS(&ba.bparent[ra], ra, rb);
+          if (old == ra)
+            break;
+          ra = old;
+        }
+        rv = min(ra, rb);
+      }
     }
   }
 }

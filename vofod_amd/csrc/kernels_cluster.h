@@ -338,44 +338,75 @@ __global__ __launch_bounds__(256) void k_mapbits(const float* __restrict__ map, 
 
 // K9: hasCloseTo (voxel_map.cpp:376-400) for every voxel against the occupancy image.
 // A cluster is close iff any member is (vofod_nodelet.cpp:727-748).
+// Phase A: every lane tests the x-run through its own map cell (in a warm map nearly every background
+// voxel hits there).  Phase B: the voxels still undecided are taken one at a time by the whole wave, each
+// lane testing rows lane, lane+64, ... of the stencil, so a true negative costs n_rows/64 row tests per
+// lane instead of n_rows serial ones and divergence does not hold finished lanes hostage.
+__device__ __forceinline__ bool close_row_hit(const MapGeom& mg, const unsigned long long* __restrict__ mapbits, const CloseRow row, int ox, int oy, int oz)
+{
+  const int y = oy + row.dy, z = oz + row.dz;
+  if (y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
+    return false;
+  const int lo = max(ox + row.x_lo, 0), hi = min(ox + row.x_hi, mg.sx - 1);
+  if (lo > hi)
+    return false;
+  const uint64_t L = (static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + lo;
+  const int nbits = hi - lo + 1;
+  const uint64_t wi = L >> 6;
+  const int sh = L & 63;
+  unsigned long long win = mapbits[wi] >> sh;
+  if (sh + nbits > 64)
+    win |= mapbits[wi + 1] << (64 - sh);
+  win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+  return win != 0ull;
+}
+
 __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows,
                                                   const FrameHdr* hdrs, const unsigned long long* __restrict__ mapbits, VoxelArrays va_all,
                                                   const uint32_t* labels_all)
 {
   const FrameHdr& h = hdrs[blockIdx.y];
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= h.V)
-    return;
+  const bool active = v < h.V;
   const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  const uint32_t root = labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v];
-  if (va.cclose[root])
-    return;  // another member already decided (possibly stale read: only costs time)
-  const float4 p = va.pts[v];
-  // coordToIdx voxel_map.cpp:592-599
-  const int ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
-  const int oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
-  const int oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
-  for (int r = 0; r < cp.n_rows; r++)
+  const int lane = threadIdx.x & 63;
+  uint32_t root = 0;
+  int ox = 0, oy = 0, oz = 0;
+  bool undecided = false;
+  if (active)
   {
-    const CloseRow row = rows[r];
-    const int y = oy + row.dy, z = oz + row.dz;
-    if (y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
-      continue;
-    const int lo = max(ox + row.x_lo, 0), hi = min(ox + row.x_hi, mg.sx - 1);
-    if (lo > hi)
-      continue;
-    const uint64_t L = (static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + lo;
-    const int nbits = hi - lo + 1;
-    const uint64_t wi = L >> 6;
-    const int sh = L & 63;
-    unsigned long long win = mapbits[wi] >> sh;
-    if (sh + nbits > 64)
-      win |= mapbits[wi + 1] << (64 - sh);
-    win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
-    if (win)
+    root = labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v];
+    if (!__hip_atomic_load(&va.cclose[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     {
-      va.cclose[root] = 1u;
-      return;
+      const float4 p = va.pts[v];
+      // coordToIdx voxel_map.cpp:592-599
+      ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
+      oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
+      oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
+      if (cp.n_rows > 0 && close_row_hit(mg, mapbits, rows[0], ox, oy, oz))  // rows[0] is (dy,dz) = (0,0): nearest first
+        __hip_atomic_store(&va.cclose[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        undecided = true;
+    }
+  }
+  unsigned long long todo = __ballot(undecided);
+  uint32_t known_close = 0xffffffffu;  // a root this wave has just proven close
+  while (todo)
+  {
+    const int src = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1;
+    const uint32_t r_root = __shfl(root, src);
+    if (r_root == known_close)
+      continue;
+    const int sx_ = __shfl(ox, src), sy_ = __shfl(oy, src), sz_ = __shfl(oz, src);
+    bool hit = false;
+    for (int r = 1 + lane; r < cp.n_rows && !hit; r += 64)
+      hit = close_row_hit(mg, mapbits, rows[r], sx_, sy_, sz_);
+    if (__ballot(hit))
+    {
+      known_close = r_root;
+      if (lane == 0)
+        __hip_atomic_store(&va.cclose[r_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -215,7 +215,21 @@ __global__ void k_grid(const GridParams g, FrameHdr* hdrs)
   }
 }
 
-// K4b: mark occupied cells.  One 64-bit atomic OR per point, skipped when the bit is already set.
+// Segmented reduction over runs of consecutive lanes holding the same key `w` (LiDAR points arrive in ring
+// order, so neighbouring lanes mostly fall into the same voxel / bitmap word).  After the call the first lane
+// of every run (`head`) holds the OR (or the sum) of the run.
+__device__ __forceinline__ bool run_heads(uint32_t w, int lane, int& end)
+{
+  const uint32_t prev = __shfl_up(w, 1);
+  const bool head = lane == 0 || prev != w;
+  const unsigned long long H = __ballot(head);
+  const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1));
+  end = above ? lane + 1 + (__ffsll(static_cast<long long>(above)) - 1) : 64;
+  return head;
+}
+
+// K4b: mark occupied cells.  One 64-bit atomic OR per run of lanes that hit the same bitmap word, skipped
+// when the bits are already set.
 __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, unsigned long long* bitmaps)
 {
   const FrameArgs& a = args[blockIdx.y];
@@ -223,17 +237,33 @@ __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const Gr
   if (h.n_in == 0)
     return;
   unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_round = (a.n + 63u) & ~63u;  // whole waves stay in the loop: the shuffles need every lane
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x)
   {
     float q[3];
-    if (!fetch_point(a, g, i, q))
-      continue;
-    const uint32_t key = cell_key(h, g, q);
-    if (key >= h.n_cells)
-      continue;  // rounding artefact outside the lattice (the reference would alias it onto another cell)
-    const unsigned long long bit = 1ull << (key & 63);
-    if (!(bm[key >> 6] & bit))
-      atomicOr(&bm[key >> 6], bit);
+    uint32_t word = 0xffffffffu;
+    unsigned long long bits = 0ull;
+    if (i < a.n && fetch_point(a, g, i, q))
+    {
+      const uint32_t key = cell_key(h, g, q);
+      if (key < h.n_cells)  // else: rounding artefact outside the lattice (the reference would alias it onto another cell)
+      {
+        word = key >> 6;
+        bits = 1ull << (key & 63);
+      }
+    }
+    int end;
+    const bool head = run_heads(word, lane, end);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1)
+    {
+      const unsigned long long t = __shfl_down(bits, s);
+      if (lane + s < end)
+        bits |= t;
+    }
+    if (head && word != 0xffffffffu && (bm[word] & bits) != bits)
+      atomicOr(&bm[word], bits);
   }
 }
 
@@ -356,6 +386,9 @@ __device__ __forceinline__ VoxelArrays frame_voxels(const VoxelArrays& base, uin
 
 // K6: phase c of the scan fused with the emission of the weighted cloud in key order
 // (voxel_grid_weighted.cpp:155-188): centre = (ijk + 0.5)*leaf + offset, weight filled by k_count.
+// Emission is load-balanced: the block's words and per-thread rank offsets are staged in LDS and every
+// thread then produces output slots t, t+256, ... (locating the owning word by binary search), so the
+// voxel records leave the CU as coalesced 16-byte-per-lane stores regardless of how the set bits cluster.
 __global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
                                               uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all)
 {
@@ -365,52 +398,82 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr
   const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
   uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
   const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  const uint32_t w0 = blockIdx.x * SCAN_WPB + threadIdx.x * SCAN_WPT;
+  const uint32_t wbase = blockIdx.x * SCAN_WPB;
+  const uint32_t w0 = wbase + threadIdx.x * SCAN_WPT;
+  __shared__ unsigned long long s_words[SCAN_WPB];
+  __shared__ uint32_t s_start[256 + 1];
+  __shared__ uint32_t lds4[4];
   unsigned long long words[SCAN_WPT];
   uint32_t c = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_WPT; k++)
   {
     words[k] = (w0 + k < h.n_words) ? bm[w0 + k] : 0ull;
+    s_words[threadIdx.x * SCAN_WPT + k] = words[k];
     c += __popcll(words[k]);
   }
-  __shared__ uint32_t lds4[4];
   uint32_t total;
-  uint32_t rank = block_excl_scan_256(c, lds4, &total) + blocksums[static_cast<size_t>(blockIdx.y) * nblk_cap + blockIdx.x];
-  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
-#pragma unroll
-  for (int k = 0; k < SCAN_WPT; k++)
+  const uint32_t excl = block_excl_scan_256(c, lds4, &total);
+  const uint32_t base = blocksums[static_cast<size_t>(blockIdx.y) * nblk_cap + blockIdx.x];
+  s_start[threadIdx.x] = excl;
+  if (threadIdx.x == 0)
+    s_start[256] = total;
   {
-    if (w0 + k < h.n_words)
-      wprefix[w0 + k] = rank;
-    unsigned long long w = words[k];
-    while (w)
-    {
-      const int b = __ffsll(static_cast<long long>(w)) - 1;
-      w &= w - 1;
-      const uint32_t key = (w0 + k) * 64u + b;
-      const int k2 = key / dxy;
-      const int rem = key - k2 * dxy;
-      const int k1 = rem / dx;
-      const int k0 = rem - k1 * dx;
-      float4 p;
-      p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
-      p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
-      p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
-      p.w = __uint_as_float(0u);
-      va.pts[rank] = p;
-      va.key[rank] = key;
-      va.parent[rank] = rank;
-      va.csize[rank] = 0;
-      va.cclose[rank] = 0;
+    uint32_t run = base + excl;
 #pragma unroll
-      for (int c3 = 0; c3 < 3; c3++)
-      {
-        va.cbox[6 * rank + c3] = 0x7fffffff;
-        va.cbox[6 * rank + 3 + c3] = static_cast<int>(0x80000000u);
-      }
-      rank++;
+    for (int k = 0; k < SCAN_WPT; k++)
+    {
+      if (w0 + k < h.n_words)
+        wprefix[w0 + k] = run;  // also for empty words: a neighbour window may start in one
+      run += __popcll(words[k]);
     }
+  }
+  __syncthreads();
+  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+  for (uint32_t t = threadIdx.x; t < total; t += 256)
+  {
+    // owner thread j: s_start[j] <= t < s_start[j+1]
+    int lo = 0, hi = 256;
+    while (hi - lo > 1)
+    {
+      const int mid = (lo + hi) >> 1;
+      if (s_start[mid] <= t)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    uint32_t u = t - s_start[lo];
+    int wi = lo * SCAN_WPT;
+    unsigned long long w = s_words[wi];
+    uint32_t pc = __popcll(w);
+    while (u >= pc)
+    {
+      u -= pc;
+      w = s_words[++wi];
+      pc = __popcll(w);
+    }
+    for (uint32_t q = 0; q < u; q++)
+      w &= w - 1;
+    const int b = __ffsll(static_cast<long long>(w)) - 1;
+    const uint32_t key = (wbase + wi) * 64u + b;
+    const uint32_t rank = base + t;
+    const int k2 = key / dxy;
+    const int rem = key - k2 * dxy;
+    const int k1 = rem / dx;
+    const int k0 = rem - k1 * dx;
+    float4 p;
+    p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
+    p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
+    p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+    p.w = __uint_as_float(0u);
+    va.pts[rank] = p;
+    va.key[rank] = key;
+    va.parent[rank] = rank;
+    va.csize[rank] = 0;
+    va.cclose[rank] = 0;
+    int* cb = &va.cbox[6 * rank];
+    cb[0] = cb[1] = cb[2] = 0x7fffffff;
+    cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
   }
 }
 
@@ -420,7 +483,8 @@ __device__ __forceinline__ uint32_t rank_of(const unsigned long long* bm, const 
   return wprefix[w] + __popcll(bm[w] & ((1ull << (key & 63)) - 1ull));
 }
 
-// K6 weights: number of input points per voxel (voxel_grid_weighted.cpp:181), integer atomics on rank slots.
+// K6 weights: number of input points per voxel (voxel_grid_weighted.cpp:181), integer atomics on rank slots,
+// one per run of lanes that fall into the same voxel.
 // `pt_rank` (nullable) records each input point's voxel rank (0xffffffff when dropped) for the counted grid.
 __global__ __launch_bounds__(256) void k_count(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps,
                                                const uint32_t* wprefix_all, VoxelArrays va_all, uint32_t* pt_rank, uint32_t pt_cap)
@@ -432,20 +496,26 @@ __global__ __launch_bounds__(256) void k_count(const FrameArgs* args, const Grid
   const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
   const uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
   const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_round = (a.n + 63u) & ~63u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x)
   {
     float q[3];
-    uint32_t r = 0xffffffffu;
-    if (fetch_point(a, g, i, q))
+    uint32_t key = 0xffffffffu;
+    if (i < a.n && fetch_point(a, g, i, q))
     {
-      const uint32_t key = cell_key(h, g, q);
-      if (key < h.n_cells)
-      {
-        r = rank_of(bm, wprefix, key);
-        atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[r].w), 1u);
-      }
+      key = cell_key(h, g, q);
+      if (key >= h.n_cells)
+        key = 0xffffffffu;
     }
-    if (pt_rank)
+    int end;
+    const bool head = run_heads(key, lane, end);
+    uint32_t r = 0xffffffffu;
+    if (key != 0xffffffffu)
+      r = rank_of(bm, wprefix, key);
+    if (head && key != 0xffffffffu)
+      atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[r].w), static_cast<uint32_t>(end - lane));
+    if (pt_rank && i < a.n)
       pt_rank[static_cast<size_t>(blockIdx.y) * pt_cap + i] = r;
   }
 }

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "host_tail.h"
 #include "kernels_brick.h"
+#include "kernels_classify.h"
 #include "kernels_cluster.h"
 #include "kernels_raycast.h"
 #include "kernels_voxelize.h"
@@ -27,8 +28,8 @@ using namespace vk;
 namespace
 {
 
-constexpr uint32_t SPEC_C = 512;   // cluster records read back speculatively with the header
-constexpr uint32_t SPEC_M = 2048;  // candidate members read back speculatively
+constexpr uint32_t SPEC_C = 192;   // cluster records read back speculatively with the header
+constexpr uint32_t SPEC_M = 768;  // candidate members read back speculatively
 
 struct CandMemberX
 {
@@ -232,6 +233,17 @@ struct Workspace
   }
 };
 
+struct ExploreBufs
+{
+  uint32_t F = 0;
+  size_t jobs_cap = 0, members_cap = 0;
+  unsigned long long* d_overlay = nullptr;
+  uint32_t *d_stack = nullptr, *d_explored = nullptr, *d_touched = nullptr, *d_ovl_list = nullptr, *d_ovl_count = nullptr, *d_job_begin = nullptr;
+  vc::ExploreJob* d_jobs = nullptr;
+  vc::ExploreResult* d_results = nullptr;
+  int* d_members = nullptr;
+};
+
 struct HostCluster
 {
   ClusterRec rec;
@@ -268,6 +280,7 @@ struct vofod_handle
   uint8_t* d_mask = nullptr;
 
   Workspace ws, aux, sepws;
+  ExploreBufs explore;
   struct ClusterTables
   {
     bool valid = false;
@@ -715,7 +728,11 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     BrickParams bp = ct->bp;
     bp.bricks_cap = ws.bricks_cap;
     KLAUNCH(h, k_brick_set, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
-    KLAUNCH(h, k_brick_union, dim3(gv, n), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
+    static const int blanes = std::getenv("VOFOD_BRICK_LANES") ? std::atoi(std::getenv("VOFOD_BRICK_LANES")) : 1;
+    if (blanes == 4)
+      KLAUNCH(h, k_brick_union<4>, dim3(gv * 4, n), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
+    else
+      KLAUNCH(h, k_brick_union<1>, dim3(gv, n), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
     KLAUNCH(h, k_brick_min, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba, ws.d_labels);
     KLAUNCH(h, k_flatten<1>, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba.bmin, ws.bricks_cap);
     KLAUNCH(h, k_brick_clear, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.ba);
@@ -755,6 +772,156 @@ float map_cmax(const vofod_handle* h)
 
 int raycast_begin_locked(vofod_handle* h, const vofod_scan* scan, const float tf[12]);
 int raycast_finish_locked(vofod_handle* h);
+
+int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
+{
+  ExploreBufs& eb = h->explore;
+  const size_t ovl_words = (h->mg.n + 63) / 64;
+  if (eb.F < F)
+  {
+    for (void* p : {static_cast<void*>(eb.d_overlay), static_cast<void*>(eb.d_stack), static_cast<void*>(eb.d_explored), static_cast<void*>(eb.d_touched),
+                    static_cast<void*>(eb.d_ovl_list), static_cast<void*>(eb.d_ovl_count), static_cast<void*>(eb.d_job_begin)})
+      if (p)
+        (void)hipFree(p);
+    eb.F = F;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_overlay), sizeof(unsigned long long) * ovl_words * F));
+    HIPCHK(hipMemset(eb.d_overlay, 0, sizeof(unsigned long long) * ovl_words * F));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_stack), sizeof(uint32_t) * vc::EX_CELLS * F));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_explored), sizeof(uint32_t) * vc::EX_CELLS * F));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_touched), sizeof(uint32_t) * vc::EX_CELLS * F));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_ovl_list), sizeof(uint32_t) * vc::EX_CELLS * F));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_ovl_count), sizeof(uint32_t) * F));
+    HIPCHK(hipMemset(eb.d_ovl_count, 0, sizeof(uint32_t) * F));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_job_begin), sizeof(uint32_t) * (F + 1)));
+  }
+  if (eb.jobs_cap < n_jobs)
+  {
+    if (eb.d_jobs)
+      (void)hipFree(eb.d_jobs);
+    if (eb.d_results)
+      (void)hipFree(eb.d_results);
+    eb.jobs_cap = std::max<size_t>(n_jobs * 2, 1024);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_jobs), sizeof(vc::ExploreJob) * eb.jobs_cap));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_results), sizeof(vc::ExploreResult) * eb.jobs_cap));
+  }
+  if (eb.members_cap < n_members)
+  {
+    if (eb.d_members)
+      (void)hipFree(eb.d_members);
+    eb.members_cap = std::max<size_t>(n_members * 2, 1 << 16);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_members), sizeof(int) * 3 * eb.members_cap));
+  }
+  return VOFOD_OK;
+}
+
+// Fallback of k_explore for one frame: the same flood fills and sums on read-back boxes of the map.
+int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, std::map<uint32_t, std::vector<vt::Member>>& by_root, const std::vector<int>& job_of,
+                       const std::vector<vc::ExploreJob>& jobs, std::vector<vc::ExploreResult>& results, bool no_update, float thr_frontiers, float thr_new)
+{
+  const vofod_dyn_params& dp = h->dp;
+  std::vector<uint64_t> pending;  // voxels this scan's classification turned into frontiers (:1712-1715)
+  auto unlin = [&](uint64_t li, int i3[3]) {
+    i3[0] = static_cast<int>(li % h->hg.s[0]);
+    i3[1] = static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]);
+    i3[2] = static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]));
+  };
+  for (size_t ci = 0; ci < cl.size(); ci++)
+  {
+    const int ji = job_of[ci];
+    if (ji < 0)
+      continue;
+    const vc::ExploreJob& job = jobs[ji];
+    const std::vector<vt::Member>& mem = by_root[cl[ci].rec.root];
+    const int R = job.R;
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; a++)
+    {
+      lo[a] = INT32_MAX;
+      hi[a] = INT32_MIN;
+    }
+    for (const vt::Member& m : mem)
+    {
+      int o[3];
+      h->hg.coordToIdx(m.p, o);
+      for (int a = 0; a < 3; a++)
+      {
+        lo[a] = std::min(lo[a], o[a] - R - 1);
+        hi[a] = std::max(hi[a], o[a] + R + 1);
+      }
+    }
+    vt::Box box;
+    int r = read_box(h, h->d_map, lo, hi, box);
+    if (r != VOFOD_OK)
+      return r;
+    for (const uint64_t li : pending)
+    {
+      int i3[3];
+      unlin(li, i3);
+      if (box.has(i3))
+        box.v[box.at(i3)] = thr_frontiers;
+    }
+    bool is_floating = true;
+    std::vector<uint64_t> explored;
+    for (const vt::Member& m : mem)
+    {
+      if (vt::explore_to_ground(h->hg, box, m.p, thr_frontiers, thr_new, static_cast<float>(R), explored))
+      {
+        is_floating = false;
+        break;
+      }
+      for (const uint64_t li : explored)
+      {
+        int i3[3];
+        unlin(li, i3);
+        box.v[box.at(i3)] = thr_frontiers;
+        pending.push_back(li);
+      }
+    }
+    results[ji].floating = is_floating;
+  }
+  if (!no_update && !pending.empty())
+  {
+    const int r = scatter_set(h, h->d_map, pending, thr_frontiers);
+    if (r != VOFOD_OK)
+      return r;
+    h->mapbits_valid = false;
+  }
+  // uncertainty sums (:851-865) after every frontier write of the frame
+  for (size_t ci = 0; ci < cl.size(); ci++)
+  {
+    const int ji = job_of[ci];
+    if (ji < 0 || !results[ji].floating)
+      continue;
+    const vc::ExploreJob& job = jobs[ji];
+    const std::vector<vt::Member>& mem = by_root[cl[ci].rec.root];
+    int mn[3] = {job.box_lo[0], job.box_lo[1], job.box_lo[2]}, mx[3] = {job.box_hi[0], job.box_hi[1], job.box_hi[2]};
+    vt::Box sub;
+    const int r = read_box(h, h->d_map, mn, mx, sub);
+    if (r != VOFOD_OK)
+      return r;
+    if (no_update)
+      for (const uint64_t li : pending)
+      {
+        int i3[3];
+        unlin(li, i3);
+        if (sub.has(i3))
+          sub.v[sub.at(i3)] = thr_frontiers;
+      }
+    const float ray = static_cast<float>(dp.voxel_map__scores__ray);
+    for (const vt::Member& m : mem)
+    {
+      int o[3];
+      h->hg.coordToIdx(m.p, o);
+      if (sub.has(o))
+        sub.v[sub.at(o)] = ray;
+    }
+    double u = 0.0;
+    for (const float val : sub.v)
+      u += 1.0 - val / dp.voxel_map__scores__ray;
+    results[ji].conf_sum = u;
+  }
+  return VOFOD_OK;
+}
 
 // The body of processMsg (vofod_nodelet.cpp:926-965) for n frames.
 int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, uint32_t n, int flags, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame,
@@ -887,67 +1054,78 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       (void)hipEventDestroy(e);
   }
 
-  // ---- host tail: classifyClusters :961 + extractDetections :963 per frame
+  // ---- tail: classifyClusters :961 + extractDetections :963.
+  // Host: canonical cluster order, OBB + gates of the few candidate clusters.  Device (k_explore): the flood
+  // fills and uncertainty sums, one wave per frame, jobs of a frame in the reference's order.
   const auto t_tail = clk::now();
-  size_t total = 0;
   const float thr_frontiers = static_cast<float>(dp.voxel_map__thresholds__frontiers);
+  struct FrameTail
+  {
+    std::vector<HostCluster> cl;
+    std::map<uint32_t, std::vector<vt::Member>> by_root;
+    std::vector<int> job_of;  // per cluster: index into jobs or -1
+    bool host_fallback = false;
+  };
+  std::vector<FrameTail> tails(n);
+  std::vector<vc::ExploreJob> jobs;
+  std::vector<uint32_t> job_begin(n + 1, 0);
+  std::vector<int> job_members;
+  const bool latches = h->background_pts_sufficient && h->sure_background_sufficient;
   for (uint32_t f = 0; f < n; f++)
   {
+    FrameTail& T = tails[f];
     const PackedFrame& pf = ws.h_packed[f];
     const FrameHdr& hdr = pf.hdr;
     if (hdr.status != VOFOD_OK)
       ret = hdr.status;
-    // cluster table
     std::vector<ClusterRec> recs(hdr.C);
     if (hdr.C <= SPEC_C)
       std::copy(pf.table, pf.table + hdr.C, recs.begin());
     else
-    {
       HIPCHK(hipMemcpy(recs.data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
-    }
     const CandMemberX* members = pf.members;
+    std::vector<CandMemberX> members_big;
     if (hdr.n_cand > SPEC_M)
     {
-      h->h_members_big.resize(hdr.n_cand);
+      members_big.resize(hdr.n_cand);
       CandMemberX* d_tmp = nullptr;
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_tmp), sizeof(CandMemberX) * hdr.n_cand));
       KLAUNCH(h, k_gather_members, dim3((hdr.n_cand + 255) / 256), dim3(256), g, f, hdr.n_cand, ws.d_cand, ws.va, d_tmp);
-      HIPCHK(hipMemcpyAsync(h->h_members_big.data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(members_big.data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       (void)hipFree(d_tmp);
-      members = h->h_members_big.data();
+      members = members_big.data();
     }
     // canonical order: size desc, smallest member asc
-    std::vector<HostCluster> cl(hdr.C);
+    T.cl.resize(hdr.C);
     for (uint32_t c = 0; c < hdr.C; c++)
-      cl[c].rec = recs[c];
-    std::sort(cl.begin(), cl.end(), [](const HostCluster& a, const HostCluster& b) {
+      T.cl[c].rec = recs[c];
+    std::sort(T.cl.begin(), T.cl.end(), [](const HostCluster& a, const HostCluster& b) {
       if (a.rec.size != b.rec.size)
         return a.rec.size > b.rec.size;
       return a.rec.root < b.rec.root;
     });
-    std::map<uint32_t, std::vector<vt::Member>> by_root;
     for (uint32_t i = 0; i < hdr.n_cand; i++)
     {
       const CandMemberX& m = members[i];
-      by_root[m.root].push_back(vt::Member{m.v, {m.x, m.y, m.z}, m.count});
+      T.by_root[m.root].push_back(vt::Member{m.v, {m.x, m.y, m.z}, m.count});
     }
-    for (auto& kv : by_root)
+    for (auto& kv : T.by_root)
       std::sort(kv.second.begin(), kv.second.end(), [](const vt::Member& a, const vt::Member& b) { return a.v < b.v; });
-
-    std::vector<uint64_t> pending;  // voxels this scan's classification turned into frontiers (:1712-1715)
+    T.job_of.assign(hdr.C, -1);
     const float* tf = tfs + 12 * f;
     const float tpos[3] = {tf[3], tf[7], tf[11]};
-    uint32_t n_det_frame = 0;
-    // classify_cluster :1648-1730 for every far cluster, in order
-    for (HostCluster& c : cl)
+    job_begin[f] = static_cast<uint32_t>(jobs.size());
+    // classify_cluster :1648-1690: boxes and gates
+    for (uint32_t ci = 0; ci < hdr.C; ci++)
     {
+      HostCluster& c = T.cl[ci];
       if (c.rec.close)
         continue;
       c.cclass = VOFOD_CLASS_INVALID;
       if (!c.rec.cand)
         continue;  // fails min_points or cannot pass max_size (device-side gate)
-      const std::vector<vt::Member>& mem = by_root[c.rec.root];
+      const std::vector<vt::Member>& mem = T.by_root[c.rec.root];
       c.boxes = vt::boxes_of(mem);
       c.evaluated = true;
       if (static_cast<int>(mem.size()) < dp.classification__min_points)
@@ -964,64 +1142,100 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
         if (c.obb_size > dp.classification__max_size)
           continue;
       }
-      bool is_floating = true;
-      if (h->background_pts_sufficient && h->sure_background_sufficient)
+      if (!latches)  // :1694, :1719-1722
       {
-        const int R = static_cast<int>((c.obb_size + dp.classification__max_explore_distance) / sp.voxel_size);
-        // one read-back covering every member's Manhattan ball
-        int lo[3], hi[3];
-        for (int a = 0; a < 3; a++)
-        {
-          lo[a] = INT32_MAX;
-          hi[a] = INT32_MIN;
-        }
-        for (const vt::Member& m : mem)
-        {
-          int o[3];
-          h->hg.coordToIdx(m.p, o);
-          for (int a = 0; a < 3; a++)
-          {
-            lo[a] = std::min(lo[a], o[a] - R - 1);
-            hi[a] = std::max(hi[a], o[a] + R + 1);
-          }
-        }
-        vt::Box box;
-        r = read_box(h, h->d_map, lo, hi, box);
-        if (r != VOFOD_OK)
-          return r;
-        for (const uint64_t li : pending)
-        {
-          const int i3[3] = {static_cast<int>(li % h->hg.s[0]), static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]), static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]))};
-          if (box.has(i3))
-            box.v[box.at(i3)] = thr_frontiers;
-        }
-        std::vector<uint64_t> explored;
-        for (const vt::Member& m : mem)
-        {
-          const bool connected = vt::explore_to_ground(h->hg, box, m.p, thr_frontiers, thr_new, static_cast<float>(R), explored);
-          if (connected)
-          {
-            is_floating = false;
-            break;
-          }
-          for (const uint64_t li : explored)
-          {
-            const int i3[3] = {static_cast<int>(li % h->hg.s[0]), static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]), static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]))};
-            box.v[box.at(i3)] = thr_frontiers;
-            pending.push_back(li);
-          }
-        }
+        c.cclass = VOFOD_CLASS_UNKNOWN;
+        continue;
       }
-      else
-        is_floating = false;
-      c.cclass = is_floating ? VOFOD_CLASS_MAV : VOFOD_CLASS_UNKNOWN;
+      vc::ExploreJob job{};
+      job.frame = f;
+      job.n_members = static_cast<uint32_t>(mem.size());
+      job.member_off = static_cast<uint32_t>(job_members.size() / 3);
+      job.R = static_cast<int>((c.obb_size + dp.classification__max_explore_distance) / sp.voxel_size);  // :1696
+      for (const vt::Member& m : mem)
+      {
+        int o[3];
+        h->hg.coordToIdx(m.p, o);
+        job_members.insert(job_members.end(), o, o + 3);
+      }
+      int mn[3], mx[3];  // getSubmapCopy(aabb, inflate 2) voxel_map.cpp:550-559
+      h->hg.coordToIdx(c.boxes.aabb_min, mn);
+      h->hg.coordToIdx(c.boxes.aabb_max, mx);
+      for (int a = 0; a < 3; a++)
+      {
+        job.box_lo[a] = std::clamp(mn[a] - 2, 0, h->hg.s[a] - 1);
+        job.box_hi[a] = std::clamp(mx[a] + 2, 0, h->hg.s[a] - 1);
+      }
+      job.result_slot = static_cast<uint32_t>(jobs.size());
+      if (job.R > vc::EX_MAX_R || job.R < 0)
+        T.host_fallback = true;
+      T.job_of[ci] = static_cast<int>(jobs.size());
+      jobs.push_back(job);
+    }
+    if (jobs.size() - job_begin[f] > vc::EX_MAX_JOBS)
+      T.host_fallback = true;
+  }
+  job_begin[n] = static_cast<uint32_t>(jobs.size());
+
+  std::vector<vc::ExploreResult> results(jobs.size());
+  static const bool force_host = std::getenv("VOFOD_EXPLORE") && std::strcmp(std::getenv("VOFOD_EXPLORE"), "host") == 0;  // tests exercise the fallback
+  bool any_host = force_host;
+  for (const FrameTail& T : tails)
+    any_host |= T.host_fallback;
+  if (!jobs.empty() && !any_host)
+  {
+    r = ensure_explore(h, ws.F, jobs.size(), job_members.size() / 3);
+    if (r != VOFOD_OK)
+      return r;
+    ExploreBufs& eb = h->explore;
+    HIPCHK(hipMemcpyAsync(eb.d_jobs, jobs.data(), sizeof(vc::ExploreJob) * jobs.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(eb.d_job_begin, job_begin.data(), sizeof(uint32_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(eb.d_members, job_members.data(), sizeof(int) * job_members.size(), hipMemcpyHostToDevice, h->stream));
+    vc::ExploreParams ep{};
+    ep.thr_unknown = thr_frontiers;
+    ep.thr_ground = thr_new;
+    ep.frontier_value = thr_frontiers;
+    ep.ray_score = dp.voxel_map__scores__ray;
+    ep.no_update = no_update;
+    ep.stack_cap = vc::EX_CELLS;
+    KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, eb.d_job_begin, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
+            eb.d_ovl_list, eb.d_ovl_count, eb.d_results);
+    HIPCHK(hipMemcpyAsync(results.data(), eb.d_results, sizeof(vc::ExploreResult) * jobs.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!no_update)
+      h->mapbits_valid = false;
+  }
+
+  size_t total = 0;
+  for (uint32_t f = 0; f < n; f++)
+  {
+    FrameTail& T = tails[f];
+    const FrameHdr& hdr = ws.h_packed[f].hdr;
+    const float* tf = tfs + 12 * f;
+    const float tpos[3] = {tf[3], tf[7], tf[11]};
+    uint32_t n_det_frame = 0;
+    if (any_host && job_begin[f + 1] > job_begin[f])
+    {
+      // fallback (Manhattan radius or job count beyond the device kernel's limits): sequential host path over read-back boxes
+      r = host_explore_frame(h, T.cl, T.by_root, T.job_of, jobs, results, no_update, thr_frontiers, thr_new);
+      if (r != VOFOD_OK)
+        return r;
+    }
+    for (uint32_t ci = 0; ci < hdr.C; ci++)
+    {
+      HostCluster& c = T.cl[ci];
+      const int ji = T.job_of[ci];
+      if (ji < 0)
+        continue;
+      c.cclass = results[ji].floating ? VOFOD_CLASS_MAV : VOFOD_CLASS_UNKNOWN;
     }
     // extractDetections :834-879
-    for (HostCluster& c : cl)
+    for (uint32_t ci = 0; ci < hdr.C; ci++)
     {
+      HostCluster& c = T.cl[ci];
       if (c.rec.close || c.cclass != VOFOD_CLASS_MAV)
         continue;
-      const std::vector<vt::Member>& mem = by_root[c.rec.root];
+      const std::vector<vt::Member>& mem = T.by_root[c.rec.root];
       vofod_detection det{};
       const float d[3] = {tpos[0] - c.boxes.obb_center[0], tpos[1] - c.boxes.obb_center[1], tpos[2] - c.boxes.obb_center[2]};
       const double det_dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -1031,45 +1245,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       const float cov = static_cast<float>(std::sqrt(det_dist) * dp.output__position_sigma);
       for (int q = 0; q < 3; q++)
         det.covariance[4 * q] = cov;
-      // getSubmapCopy(aabb, inflate 2) voxel_map.cpp:547-584
-      int mn[3], mx[3];
-      h->hg.coordToIdx(c.boxes.aabb_min, mn);
-      h->hg.coordToIdx(c.boxes.aabb_max, mx);
-      for (int a = 0; a < 3; a++)
-      {
-        mn[a] = std::clamp(mn[a] - 2, 0, h->hg.s[a] - 1);
-        mx[a] = std::clamp(mx[a] + 2, 0, h->hg.s[a] - 1);
-      }
-      vt::Box sub;
-      r = read_box(h, h->d_map, mn, mx, sub);
-      if (r != VOFOD_OK)
-        return r;
-      for (const uint64_t li : pending)
-      {
-        const int i3[3] = {static_cast<int>(li % h->hg.s[0]), static_cast<int>((li / h->hg.s[0]) % h->hg.s[1]), static_cast<int>(li / (static_cast<uint64_t>(h->hg.s[0]) * h->hg.s[1]))};
-        if (sub.has(i3))
-          sub.v[sub.at(i3)] = thr_frontiers;
-      }
-      vt::Geom sg = h->hg;  // the sub-map's own geometry: offset = idxToCoord(min) - vs/2 (:563)
-      float cmin[3];
-      h->hg.idxToCoord(mn, cmin);
-      for (int a = 0; a < 3; a++)
-      {
-        sg.off[a] = cmin[a] - h->hg.vs / 2.0f;
-        sg.s[a] = sub.n[a];
-      }
-      const float ray = static_cast<float>(dp.voxel_map__scores__ray);
-      for (const vt::Member& m : mem)
-      {
-        int si[3];
-        sg.coordToIdx(m.p, si);
-        if (sg.inLimits(si))
-          sub.v[(static_cast<size_t>(si[2]) * sub.n[1] + si[1]) * sub.n[0] + si[0]] = ray;  // :853-857
-      }
-      double u = 0.0;
-      for (const float val : sub.v)
-        u += 1.0 - val / dp.voxel_map__scores__ray;  // :860-862
-      u /= mem.size();
+      const double u = results[T.job_of[ci]].conf_sum / mem.size();  // :860-865
       det.confidence = static_cast<float>(1.0 / std::exp(u));
       const double vray_res = sp.sensor_vfov / static_cast<double>(sp.sensor_vrays);
       const double hray_res = 2 * M_PI / static_cast<double>(sp.sensor_hrays);
@@ -1083,13 +1259,6 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
     }
     if (n_out_per_frame)
       n_out_per_frame[f] = n_det_frame;
-    if (!no_update && !pending.empty())
-    {
-      r = scatter_set(h, h->d_map, pending, thr_frontiers);
-      if (r != VOFOD_OK)
-        return r;
-      h->mapbits_valid = false;
-    }
 
     if (dbg)
     {
@@ -1116,7 +1285,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
         else
           for (uint32_t c = 0; c < hdr.C; c++)
           {
-            const HostCluster& hc = cl[c];
+            const HostCluster& hc = T.cl[c];
             vofod_cluster_info& ci = d.clusters[c];
             ci.first_member = hc.rec.root;
             ci.n_points = hc.rec.size;

@@ -168,10 +168,10 @@ def apriori_points(scene: Scene, voxel_size: float, n_voxels: int | None = None,
 
 # ---------------------------------------------------------------------------- scenarios
 
-def seed_ground(det, xy=(0.0, 0.0), radius: float = 3.0, value: float = -185.0):
+def seed_ground(det, xy=(0.0, 0.0), radius: float = 30.0, value: float = -185.0):
     """Stand-in for the range-finder ground seeding of processMsg(Range) (vofod_nodelet.cpp:581-613,
-    out of scope here): marks the ground voxels under the sensor as background so that the first
-    scans have something to be 'close' to.  Works on any implementation of the C-ABI."""
+    out of scope here): marks the ground voxels around the sensor as background so that the first
+    scans have something to be 'close' to (a hovering OS1 does not see the ground right below it).  Works on any implementation of the C-ABI."""
     from . import capi
 
     m = det.read_map(capi.MAP_VOXELS)
