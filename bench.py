@@ -110,23 +110,19 @@ def main():
     ]
     tfs = np.stack([s.tf for s in host_scans]).astype(np.float32)
 
-    D_MAX = 16  # detection records per frame in the all-gather payload
-    rec_local = torch.zeros((F, D_MAX * 16 + 1), dtype=torch.float64, device=dev)  # 128-B records + per-frame count
-    rec_all = torch.zeros((world, F, D_MAX * 16 + 1), dtype=torch.float64, device=dev) if world > 1 else None
-    rec_host = np.zeros((F, D_MAX * 16 + 1), dtype=np.float64)
+    from vofod_amd import dist as vdist
+
+    # all-gather payload: D_MAX 128-byte detection records + the count per frame, RCCL over xGMI
+    rec_local = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64, device=dev)
+    rec_all = torch.zeros((world, F, vdist.FRAME_F64), dtype=torch.float64, device=dev)
+    rec_host = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64).pin_memory()
 
     def step():
         dets, per = det.process_batch(scans, tfs)
         if world > 1:
-            rec_host[:] = 0
-            rec_host[:, -1] = per
-            k0 = 0
-            for f in range(F):
-                for j in range(min(int(per[f]), D_MAX)):
-                    rec_host[f, 16 * j : 16 * j + 16] = np.frombuffer(dets[k0 + j].tobytes(), dtype=np.float64)
-                k0 += int(per[f])
-            rec_local.copy_(torch.from_numpy(rec_host))
-            dist.all_gather_into_tensor(rec_all, rec_local)
+            vdist.pack_detections(dets, per, out=rec_host.numpy())
+            rec_local.copy_(rec_host, non_blocking=True)
+            vdist.allgather_detections(rec_local, rec_all)
         return dets, per
 
     def sync():
@@ -243,6 +239,12 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
     path_us = sum(kernels[p]["avg_us"] for p in path if p in kernels)
     dom = max((p for p in path if p in kernels), key=lambda p: kernels[p]["avg_us"])
     dk = kernels[dom]
+    traffic = None
+    tr_file = ROOT / "profiles" / "r01_traffic.json"
+    if tr_file.exists():  # PMC passes of this same command (tools/run_profiles.sh), corrected per MI355X_MICROARCH.md
+        tr = json.loads(tr_file.read_text())
+        if dom in tr:
+            traffic = tr[dom]["hbm_bytes_per_launch_corrected"]
     roofline = {
         "bound": "hbm",
         "kernel": dom,
@@ -250,7 +252,7 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": dk.get("GBps", 0.0) / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic,
         "alg_bytes_per_launch": dk.get("alg_bytes"),
         "avg_launch_us": dk["avg_us"],
         "path": {

@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/vofod.h declares (no compute calls: no GPU here)."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from vofod_amd import capi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_header_declares_the_expected_surface():
+    names = capi.declared_entry_points()
+    for n in ("create", "destroy", "reset", "process_scan", "process_batch", "raycast_begin", "raycast_finish", "sepclusters_begin",
+              "sepclusters_finish", "voxel_grid_weighted", "voxel_grid_counted", "cluster", "load_apriori", "read_map", "write_map",
+              "load_cloud", "sim_lut", "default_params", "set_dynamic_params", "get_status", "last_error_string"):
+        assert n in names
+    assert set(names) == set(capi._SIGS)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    so = ROOT / "vofod_amd" / "csrc" / "libvofod_hip.so"
+    if not so.exists():  # hipcc cross-compiles gfx950 without a GPU
+        subprocess.run(["make", "-C", str(so.parent)], check=True, capture_output=True)
+    lib = capi.Library(so, "vofod_")  # raises ImportError listing any missing symbol
+    for n in capi.declared_entry_points():
+        assert hasattr(lib, n)
+    # plain C types only: parameter defaults are readable without touching a device
+    sp, dp = capi.StaticParams(), capi.DynParams()
+    lib.default_params(sp, dp)
+    assert sp.voxel_size == pytest.approx(0.5) and dp.sepclusters__min_sure_points == 24
+    assert sp.sensor_hrays == 1024 and sp.sensor_vrays == 128
+
+
+def test_oracle_exports_the_same_surface(oracle):
+    sp, dp = capi.StaticParams(), capi.DynParams()
+    oracle.default_params(sp, dp)
+    assert dp.ground_points_max_distance == 1.5 and dp.raycast__weight_coefficient == 0.003
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product path must fail loudly rather than fall back: nothing under vofod_amd/ may mention oracle/"""
+    for p in (ROOT / "vofod_amd").rglob("*"):
+        if p.suffix in (".py", ".h", ".hip", ".cpp") and p.name != "capi.py":
+            text = p.read_text()
+            assert "libvofod_oracle" not in text and "oracle/" not in text.replace("oracle/.", ""), p
+
+
+def test_library_loader_fails_loudly_when_missing(monkeypatch, tmp_path):
+    import vofod_amd
+
+    monkeypatch.setattr(vofod_amd, "_lib", None)
+    monkeypatch.setattr(vofod_amd, "LIB_PATH", tmp_path / "libvofod_hip.so")
+    with pytest.raises(ImportError):
+        vofod_amd.library()

@@ -1,0 +1,55 @@
+"""Property tests of the oracle: conservation, permutation invariance, clustering vs brute force."""
+import ctypes as C
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from vofod_amd import capi
+from vofod_amd.detector import cluster, voxel_grid_counted, voxel_grid_weighted
+
+
+def _cloud(seed, n, span):
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-span, span, size=(n, 3))).astype(np.float32)
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10_000), n=st.integers(1, 3000), leaf=st.sampled_from([0.1, 0.25, 0.5, 1.0, 3.0]), aligned=st.booleans())
+def test_weighted_grid_conserves_points_and_is_permutation_invariant(oracle, seed, n, leaf, aligned):
+    q = _cloud(seed, n, 20.0)
+    align = (-19.75, -29.75, -1.0) if aligned else None
+    out, keys, grid, _ = voxel_grid_weighted(oracle, q[:, 0], q[:, 1], q[:, 2], leaf, align)
+    assert int(out["range"].sum()) == n
+    assert np.all(np.diff(keys.astype(np.int64)) > 0)  # strictly ascending lattice keys
+    perm = np.random.default_rng(seed + 1).permutation(n)
+    out2, keys2, _, _ = voxel_grid_weighted(oracle, q[perm, 0], q[perm, 1], q[perm, 2], leaf, align)
+    np.testing.assert_array_equal(keys2, keys)
+    np.testing.assert_array_equal(out2.view(np.uint32), out.view(np.uint32))
+    # every input point lies inside its voxel: |p - centre| <= leaf/2 (+ rounding)
+    dx = np.array(list(grid.div_b))
+    assert int(keys.max()) < int(dx[0]) * int(dx[1]) * int(dx[2])
+
+
+@settings(max_examples=15, deadline=None)
+@given(seed=st.integers(0, 10_000), n=st.integers(1, 2000), thr=st.sampled_from([-100.0, -0.1, 0.5]))
+def test_counted_grid_total_is_the_true_total(oracle, seed, n, thr):
+    q = np.floor(_cloud(seed, n, 30.0)).astype(np.float32)
+    inten = np.random.default_rng(seed).uniform(-200, 10, size=n).astype(np.float32)
+    out, keys, _, _ = voxel_grid_counted(oracle, q[:, 0], q[:, 1], q[:, 2], inten, 3.0, thr)
+    assert int(out["range"].sum()) == int((inten > thr).sum())  # the positional ranges still tile [0, n)
+
+
+@settings(max_examples=15, deadline=None)
+@given(seed=st.integers(0, 10_000), n=st.integers(2, 600), tol=st.sampled_from([0.7, 1.5, 2.0]))
+def test_cluster_labels_match_bruteforce_union_find(oracle, seed, n, tol):
+    q = _cloud(seed, n, 6.0)
+    pts, keys, grid, _ = voxel_grid_weighted(oracle, q[:, 0], q[:, 1], q[:, 2], 0.5)
+    labels, nc = cluster(oracle, pts, keys, grid, tol)
+    bf = oracle.extra("vofod_oracle_cluster_bruteforce", C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p])
+    ref = np.zeros(len(pts), dtype=np.uint32)
+    bf(capi.ptr(pts), len(pts), tol, capi.ptr(ref))
+    np.testing.assert_array_equal(labels, ref)
+    assert nc == len(np.unique(ref))
+    # labels are canonical: the smallest member of each component
+    for l in np.unique(labels):
+        assert np.flatnonzero(labels == l)[0] == l

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Reduces rocprofv3 CSV output (gpurun_out/prof_<tag>/{stats,fetch,write}) to small committed summaries:
+profiles/<tag>_kernel_stats.csv (the --stats table) and profiles/<tag>_traffic.json (HBM bytes per launch per
+kernel from the FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md §HBM prescribes)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(k_\w+)(<\d+>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:48]
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    os.makedirs("profiles", exist_ok=True)
+    stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+            f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
+            for r in rows:
+                f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+    traffic = defaultdict(lambda: {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+    for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for path in glob.glob(f"{src}/{which}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(path)):
+                if r.get("Counter_Name") != ctr:
+                    continue
+                k = short(r["Kernel_Name"])
+                traffic[k][ctr] += float(r["Counter_Value"])
+                if ctr == "FETCH_SIZE":
+                    traffic[k]["launches"] += 1
+    out = {}
+    for k, t in traffic.items():
+        n = max(t["launches"], 1)
+        # counters are in KiB; gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read (x2 correction,
+        # calibrated for 16-B/lane streams only: treat it as an upper estimate for scattered kernels); WRITE_SIZE is exact.
+        out[k] = {
+            "launches": n,
+            "fetch_kib_raw_per_launch": t["FETCH_SIZE"] / n,
+            "write_kib_per_launch": t["WRITE_SIZE"] / n,
+            "hbm_bytes_per_launch_raw": (t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / n,
+            "hbm_bytes_per_launch_corrected": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / n,
+        }
+    json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)
+    print("wrote", f"profiles/{tag}_kernel_stats.csv", f"profiles/{tag}_traffic.json", len(out), "kernels")
+
+
+if __name__ == "__main__":
+    main()

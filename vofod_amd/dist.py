@@ -1,0 +1,70 @@
+"""Batched many-scan mode across the GPUs of one node.
+
+Independent frames are sharded in contiguous blocks over the ranks (one process per GPU), every rank runs
+`vofod_process_batch` on its own frames against its own replica of the voxel map, and the only collective is
+one all-gather of fixed-size detection records at the end (RCCL over xGMI for CUDA tensors; gloo on CPU in the
+tests).  The payload is tiny (D_MAX x 128 B + 8 B per frame), so the call is latency bound.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+
+D_MAX = 16                      # detection records carried per frame
+REC_F64 = capi.DETECTION.itemsize // 8   # a 128-byte vofod_detection viewed as 16 float64 words
+FRAME_F64 = D_MAX * REC_F64 + 1          # + the frame's detection count
+
+
+def shard_frames(n_frames: int, world: int, rank: int) -> range:
+    """Contiguous block of frame indices owned by `rank` (frame f -> rank f // ceil(n/world))."""
+    per = -(-n_frames // world)
+    return range(min(rank * per, n_frames), min((rank + 1) * per, n_frames))
+
+
+def pack_detections(dets: np.ndarray, per_frame: np.ndarray, out: np.ndarray | None = None) -> np.ndarray:
+    """[n_frames, FRAME_F64] float64: up to D_MAX records per frame followed by the true count."""
+    n = len(per_frame)
+    if out is None:
+        out = np.zeros((n, FRAME_F64), dtype=np.float64)
+    else:
+        out[:] = 0
+    out[:, -1] = per_frame
+    raw = np.frombuffer(np.ascontiguousarray(dets).tobytes(), dtype=np.float64).reshape(-1, REC_F64) if len(dets) else np.zeros((0, REC_F64))
+    k0 = 0
+    for f in range(n):
+        c = int(per_frame[f])
+        m = min(c, D_MAX)
+        if m:
+            out[f, : m * REC_F64] = raw[k0 : k0 + m].reshape(-1)
+        k0 += c
+    return out
+
+
+def unpack_detections(packed: np.ndarray, frame_offset: int = 0) -> np.ndarray:
+    """Inverse of pack_detections for one rank's block; `frame` fields are rebased by frame_offset."""
+    recs = []
+    for f in range(packed.shape[0]):
+        m = min(int(packed[f, -1]), D_MAX)
+        if m:
+            d = np.frombuffer(np.ascontiguousarray(packed[f, : m * REC_F64]).tobytes(), dtype=capi.DETECTION).copy()
+            d["frame"] = frame_offset + f
+            recs.append(d)
+    return np.concatenate(recs) if recs else np.zeros(0, dtype=capi.DETECTION)
+
+
+def allgather_detections(local, gathered=None):
+    """One all-gather of the packed records.  `local`: torch tensor [frames_per_rank, FRAME_F64] (float64) on
+    the device the process group communicates on.  Returns [world, frames_per_rank, FRAME_F64]."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if gathered is None:
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if world == 1:
+        gathered[0].copy_(local)
+    else:
+        # concatenated layout [world * frames, ...] is what every backend accepts; same memory as [world, frames, ...]
+        dist.all_gather_into_tensor(gathered.view((world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous())
+    return gathered
