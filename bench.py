@@ -225,8 +225,12 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_setbits": 12.0 * n_pts * F,
         "k_count": 12.0 * n_pts * F,
         "k_emit": 20.0 * V * F,
-        "k_union": 20.0 * V * F,
-        "k_flatten": 8.0 * V * F,
+        "k_union<2>": 20.0 * V * F,
+        "k_flatten<0>": 8.0 * V * F,
+        "k_flatten<1>": 8.0 * V * F,
+        "k_brick_set": 4.0 * V * F,
+        "k_brick_union<1>": 16.0 * V * F,  # the voxels' share of "read centres/keys 16*V" (SURVEY 8d): the bricks hold them as bits
+        "k_brick_min": 8.0 * V * F,
         "k_closefar": 4.0 * V * F,
         "k_finalize": 12.0 * V * F,
         "k_mapbits": 4.0 * M + M / 8.0,
@@ -235,9 +239,11 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         if nm in alg and k["avg_us"] > 0:
             k["alg_bytes"] = alg[nm]
             k["GBps"] = alg[nm] / (k["avg_us"] * 1e-6) / 1e9
-    path = ["k_bbox", "k_grid", "k_setbits", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten"]
-    path_us = sum(kernels[p]["avg_us"] for p in path if p in kernels)
-    dom = max((p for p in path if p in kernels), key=lambda p: kernels[p]["avg_us"])
+    # the voxelize+cluster path of north_star: K1-K7 (either clustering family)
+    path_prefixes = ("k_init_hdr", "k_bbox", "k_grid", "k_setbits", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten", "k_brick_")
+    path = [k for k in kernels if k.startswith(path_prefixes)]
+    path_us = sum(kernels[p]["avg_us"] for p in path)
+    dom = max(path, key=lambda p: kernels[p]["avg_us"])
     dk = kernels[dom]
     traffic = None
     tr_file = ROOT / "profiles" / "r01_traffic.json"
