@@ -57,6 +57,8 @@ struct GridParams
   float op_min[3], op_max[3];  // operation area, world frame (vofod_nodelet.cpp:645-648)
   uint32_t words_cap;          // bitmap words available per frame
   uint32_t vox_cap;            // voxel records available per frame
+  uint32_t n_frames;           // frames covered by the launch
+  uint32_t xcd_map;            // 1: blocks of frame f are dealt to XCD f % 8 (per-frame working set stays in one L2)
 };
 
 // One (dj,dk) row of the Euclidean-clustering half stencil.

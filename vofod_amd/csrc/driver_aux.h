@@ -593,6 +593,15 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   const uint32_t nbricks = static_cast<uint32_t>(((sizes[0] + 2 + 3) / 4) * ((sizes[1] + 2 + 3) / 4) * static_cast<uint64_t>((sizes[2] + 2 + 3) / 4));
   CREATE_CHK(h->ws.ensure(F, static_cast<uint32_t>(n), static_cast<uint32_t>(n), static_cast<uint32_t>((cells + 63) / 64), nbricks));
 #undef CREATE_CHK
+  {
+    // host workers for the per-frame tail of a batch (frames are independent); VOFOD_THREADS overrides
+    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    if (const char* e = std::getenv("VOFOD_THREADS"))
+      nt = std::max(1, std::atoi(e));
+    if (F == 1)
+      nt = 1;
+    h->pool.reset(new vt::Pool(nt));
+  }
   if (do_reset(h) != VOFOD_OK)
     return fail(VOFOD_ERR_DEVICE);
   h->sure_background_sufficient = false;  // :283-284

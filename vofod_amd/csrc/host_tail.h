@@ -51,6 +51,45 @@ struct Member
   uint32_t count;
 };
 
+// members of the candidate clusters of one frame, grouped by cluster (root) and ascending inside a group
+struct MemberSpan
+{
+  const Member* p = nullptr;
+  size_t n = 0;
+  const Member* begin() const { return p; }
+  const Member* end() const { return p + n; }
+  size_t size() const { return n; }
+  const Member& operator[](size_t i) const { return p[i]; }
+};
+
+struct MemberIndex
+{
+  std::vector<Member> all;                 // sorted by (root, v)
+  std::vector<uint32_t> roots;             // parallel to `all`
+  std::vector<std::pair<uint32_t, uint32_t>> first;  // (root, begin) sorted by root, plus a sentinel
+  void build(std::vector<std::pair<uint64_t, Member>>& tmp)
+  {
+    std::sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    all.resize(tmp.size());
+    first.clear();
+    for (size_t i = 0; i < tmp.size(); i++)
+    {
+      all[i] = tmp[i].second;
+      const uint32_t root = static_cast<uint32_t>(tmp[i].first >> 32);
+      if (first.empty() || first.back().first != root)
+        first.emplace_back(root, static_cast<uint32_t>(i));
+    }
+    first.emplace_back(0xffffffffu, static_cast<uint32_t>(tmp.size()));
+  }
+  MemberSpan of(uint32_t root) const
+  {
+    const auto it = std::lower_bound(first.begin(), first.end(), std::make_pair(root, 0u));
+    if (it == first.end() || it->first != root)
+      return MemberSpan{};
+    return MemberSpan{all.data() + it->second, static_cast<size_t>((it + 1)->second - it->second)};
+  }
+};
+
 struct Boxes
 {
   float aabb_min[3], aabb_max[3];
@@ -66,7 +105,8 @@ inline void eig3(double a[3][3], double w[3], double v[3][3])
   for (int it = 0; it < 60; it++)
   {
     const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    if (off < 1e-280)
+    const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-36 * diag || off < 1e-280)  // off-diagonal below double resolution of the diagonal (avoids denormal sweeps)
       break;
     for (int p = 0; p < 3; p++)
       for (int q = p + 1; q < 3; q++)
@@ -102,7 +142,7 @@ inline void eig3(double a[3][3], double w[3], double v[3][3])
 
 // [3P] pcl::MomentOfInertiaEstimation: mean, covariance/n^2, principal axes (major >= middle >= minor,
 // right-handed), AABB and OBB (centre = mean + R*shift).  Members are in ascending index order.
-inline Boxes boxes_of(const std::vector<Member>& m)
+inline Boxes boxes_of(const MemberSpan& m)
 {
   Boxes b;
   float mean[3] = {0, 0, 0};

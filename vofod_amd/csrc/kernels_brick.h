@@ -21,6 +21,8 @@ struct BrickOff
 {
   int8_t dx, dy, dz;
   uint8_t has_amb;
+  uint32_t pad;
+  unsigned long long ua, ub;  // bits of this brick / of the neighbour brick that have any partner at this offset
 };
 
 struct BrickParams
@@ -67,12 +69,16 @@ __device__ __forceinline__ uint32_t brick_of(const FrameHdr& h, int i, int j, in
 // mark every voxel in its brick word; the first voxel of a brick registers it
 __global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const BrickParams bp, FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all)
 {
-  FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  FrameHdr& h = hdrs[FRAME];
+  const uint32_t v = BX * blockDim.x + threadIdx.x;
   if (v >= h.V)
     return;
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
   int i, j, k, bit;
   key_to_ijk(h, va.key[v], i, j, k);
   const uint32_t b = brick_of(h, i, j, k, bit);
@@ -91,13 +97,17 @@ __global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const B
                                                      const unsigned long long* __restrict__ sure, const unsigned long long* __restrict__ amb, const FrameHdr* hdrs,
                                                      BrickArrays ba_all)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
   // BRICK_LANES lanes share one brick and split its neighbour offsets: short dependent chains, 8x the waves
-  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / BRICK_LANES;
+  const uint32_t t = (BX * blockDim.x + threadIdx.x) / BRICK_LANES;
   const int sub = threadIdx.x % BRICK_LANES;
   if (t >= h.n_bricks)
     return;
-  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
   const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2, nbz = (h.div_b[2] + 3) >> 2;
   const uint32_t b = ba.blist[t];
   const unsigned long long A = ba.bricks[b];
@@ -136,6 +146,8 @@ __global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const B
         continue;
       const int o = o0 + c;
       const BrickOff off = offs[o];
+      if (!(A & off.ua) || !(B & off.ub))
+        continue;  // no bit of either brick can reach the other at this offset
       const uint32_t nb = nbi[c];
       const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
       bool conn = false;
@@ -199,15 +211,210 @@ __global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const B
   }
 }
 
+// ---- two-phase variant for stencils of at most 64 brick offsets -------------------------------------------
+// Phase 1 (k_brick_conn): CONN_LANES lanes share a brick, split its neighbour offsets and OR their findings into one
+// 64-bit connectivity mask per brick (bit o: the occupied neighbour at offset o is within the tolerance).  No atomics,
+// no dependent chains: pure probing, spread over 8x the lanes.
+constexpr int CONN_LANES = 8;
+__global__ __launch_bounds__(256) void k_brick_conn(const GridParams g, const BrickParams bp, const BrickOff* __restrict__ offs,
+                                                    const unsigned long long* __restrict__ sure, const unsigned long long* __restrict__ amb, const FrameHdr* hdrs,
+                                                    BrickArrays ba_all, unsigned long long* __restrict__ conn_all)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t t = (BX * blockDim.x + threadIdx.x) / CONN_LANES;
+  const int sub = threadIdx.x % CONN_LANES;
+  // whole groups of CONN_LANES lanes share t, so the shuffles below see uniform participation per group
+  const bool live = t < h.n_bricks;
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
+  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2, nbz = (h.div_b[2] + 3) >> 2;
+  unsigned long long mask = 0ull;
+  if (live)
+  {
+    const uint32_t b = ba.blist[t];
+    const unsigned long long A = ba.bricks[b];
+    const int bz = b / (nbx * nby);
+    const int brem = b - bz * nbx * nby;
+    const int by = brem / nbx;
+    const int bx = brem - by * nbx;
+    for (int o = sub; o < bp.n_off; o += CONN_LANES)
+    {
+      const BrickOff off = offs[o];
+      const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
+      if (nx < 0 || nx >= nbx || ny < 0 || ny >= nby || nz >= nbz)
+        continue;
+      if (!(A & off.ua))
+        continue;
+      const unsigned long long B = ba.bricks[static_cast<uint32_t>((nz * nby + ny) * nbx + nx)];
+      if (!(B & off.ub))
+        continue;
+      bool conn = false;
+      const unsigned long long* s = sure + static_cast<size_t>(o) * 64;
+      unsigned long long a = A & off.ua;
+      while (a && !conn)
+      {
+        const int p = __ffsll(static_cast<long long>(a)) - 1;
+        a &= a - 1;
+        conn = (s[p] & B) != 0ull;
+      }
+      if (!conn && off.has_amb)
+      {
+        const unsigned long long* m = amb + static_cast<size_t>(o) * 64;
+        a = A & off.ua;
+        while (a && !conn)
+        {
+          const int p = __ffsll(static_cast<long long>(a)) - 1;
+          a &= a - 1;
+          unsigned long long cand = m[p] & B;
+          if (!cand)
+            continue;
+          const float px = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+          const float py = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+          const float pz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+          while (cand && !conn)
+          {
+            const int q = __ffsll(static_cast<long long>(cand)) - 1;
+            cand &= cand - 1;
+            const float qx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nx + (q & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+            const float qy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * ny + ((q >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+            const float qz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nz + (q >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+            const float ddx = __fsub_rn(px, qx), ddy = __fsub_rn(py, qy), ddz = __fsub_rn(pz, qz);
+            float d2 = __fmul_rn(ddx, ddx);
+            d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
+            d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
+            conn = d2 < bp.r2;
+          }
+        }
+      }
+      if (conn)
+        mask |= 1ull << o;
+    }
+  }
+#pragma unroll
+  for (int s2 = 1; s2 < CONN_LANES; s2 <<= 1)
+    mask |= __shfl_xor(mask, s2);
+  if (live && sub == 0)
+    conn_all[static_cast<size_t>(FRAME) * g.vox_cap + t] = mask;
+}
+
+// Phase 2 (k_brick_link): one lane per brick merges the brick with all its connected neighbours at once: the
+// representatives of up to LINK_K nodes are chased with independent loads, every non-minimal representative is hooked
+// under the minimum with independent compare-and-swaps, and only the nodes whose hook lost a race are resolved again.
+constexpr int LINK_K = 16;
+__global__ __launch_bounds__(256) void k_brick_link(const GridParams g, const BrickParams bp, const BrickOff* __restrict__ offs, const FrameHdr* hdrs,
+                                                    BrickArrays ba_all, const unsigned long long* __restrict__ conn_all)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t t = BX * blockDim.x + threadIdx.x;
+  if (t >= h.n_bricks)
+    return;
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
+  unsigned long long mask = conn_all[static_cast<size_t>(FRAME) * g.vox_cap + t];
+  if (!mask)
+    return;
+  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
+  const uint32_t b = ba.blist[t];
+  volatile uint32_t* parent = ba.bparent;
+  uint32_t rv = b;
+  while (mask)
+  {
+    uint32_t R[LINK_K + 1], N[LINK_K + 1];
+    int k = 1;
+    R[0] = rv;
+#pragma unroll
+    for (int i = 1; i <= LINK_K; i++)
+    {
+      R[i] = 0xffffffffu;
+      if (mask)
+      {
+        const int o = __ffsll(static_cast<long long>(mask)) - 1;
+        mask &= mask - 1;
+        const BrickOff off = offs[o];
+        R[i] = b + static_cast<uint32_t>((off.dz * nby + off.dy) * nbx + off.dx);
+        k = i + 1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i <= LINK_K; i++)
+      N[i] = R[i];
+    for (int round = 0; round < 64; round++)
+    {
+      // chase all representatives, independent loads per sweep
+      bool moving = true;
+      while (moving)
+      {
+        moving = false;
+        uint32_t P[LINK_K + 1];
+#pragma unroll
+        for (int i = 0; i <= LINK_K; i++)
+          P[i] = (i < k) ? parent[R[i]] : 0u;
+#pragma unroll
+        for (int i = 0; i <= LINK_K; i++)
+          if (i < k && P[i] != R[i])
+          {
+            R[i] = P[i];
+            moving = true;
+          }
+      }
+      uint32_t m = R[0];
+#pragma unroll
+      for (int i = 1; i <= LINK_K; i++)
+        if (i < k)
+          m = min(m, R[i]);
+      // hook every other representative under the minimum
+      bool retry = false;
+      uint32_t O[LINK_K + 1];
+#pragma unroll
+      for (int i = 0; i <= LINK_K; i++)
+        O[i] = (i < k && R[i] != m) ? atomicCAS(const_cast<uint32_t*>(&parent[R[i]]), R[i], m) : 0xffffffffu;
+#pragma unroll
+      for (int i = 0; i <= LINK_K; i++)
+        if (i < k && R[i] != m)
+        {
+          if (O[i] == R[i] || O[i] == m)
+            R[i] = m;
+          else
+          {
+            R[i] = O[i];  // lost a race: R[i] has a new parent, resolve again
+            retry = true;
+          }
+        }
+      if (!retry)
+        break;
+    }
+    // path compression: every node of this batch now hangs directly under the common representative
+#pragma unroll
+    for (int i = 0; i <= LINK_K; i++)
+      if (i < k && N[i] > R[i])
+        parent[N[i]] = R[i];
+    rv = R[0];
+#pragma unroll
+    for (int i = 1; i <= LINK_K; i++)
+      if (i < k)
+        rv = min(rv, R[i]);
+  }
+}
+
 // per voxel: representative brick of its component (stored in labels[]), smallest voxel rank per component
 __global__ __launch_bounds__(256) void k_brick_min(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all,
                                                    uint32_t* labels_all)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t v = BX * blockDim.x + threadIdx.x;
   const bool active = v < h.V;
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
   uint32_t R = 0xffffffffu;
   if (active)
   {
@@ -217,7 +424,7 @@ __global__ __launch_bounds__(256) void k_brick_min(const GridParams g, const Bri
     uint32_t p;
     while ((p = ba.bparent[R]) != R)
       R = p;
-    labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v] = R;
+    labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v] = R;
   }
   // consecutive voxels mostly share the component: one atomicMin per run of equal roots inside the wave
   const uint32_t prevR = __shfl_up(R, 1);
@@ -228,11 +435,15 @@ __global__ __launch_bounds__(256) void k_brick_min(const GridParams g, const Bri
 
 __global__ __launch_bounds__(256) void k_brick_clear(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, BrickArrays ba_all)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t t = BX * blockDim.x + threadIdx.x;
   if (t >= h.n_bricks)
     return;
-  const BrickArrays ba = frame_bricks(ba_all, blockIdx.y, bp.bricks_cap, g.vox_cap);
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
   ba.bricks[ba.blist[t]] = 0ull;
 }
 

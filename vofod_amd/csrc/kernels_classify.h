@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
 {
   __shared__ uint32_t visited[EX_WORDS];
   __shared__ uint8_t s_float[EX_MAX_JOBS];
+  __shared__ uint8_t s_walk[6 * 32];
   const int lane = threadIdx.x;
   const uint32_t slot = blockIdx.x;
   const uint32_t jb = job_begin[slot], je = job_begin[slot + 1];
@@ -123,6 +124,53 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
         }
       }
       const int ox = members[3 * (job.member_off + m)], oy = members[3 * (job.member_off + m) + 1], oz = members[3 * (job.member_off + m) + 2];
+      // Fast path: the six axis-aligned walks from the start voxel are legal paths of the fill (6-neighbour moves,
+      // Manhattan distance = step count).  If one of them runs over unknown voxels up to the rim (distance R-1) or
+      // meets a ground voxel first, the reference's fill returns "connected" whatever else it would explore, so the
+      // whole ball need not be searched.  All voxels of the six walks are fetched at once.
+      if (job.R - 1 >= 1 && job.R - 1 <= 31)
+      {
+        const int len = job.R - 1;
+        for (int e = lane; e < 6 * 32; e += 64)
+        {
+          const int q = e >> 5, d = (e & 31) + 1;
+          uint8_t st = 0;  // 0 blocked, 1 unknown, 2 ground
+          if (d <= len)
+          {
+            const int ax = ox + (q == 0 ? d : q == 3 ? -d : 0), ay = oy + (q == 1 ? d : q == 4 ? -d : 0), az = oz + (q == 2 ? d : q == 5 ? -d : 0);
+            if (ax >= 0 && ax <= mg.sx - 1 && ay >= 0 && ay <= mg.sy - 1 && az >= 0 && az <= mg.sz - 1)
+            {
+              const float v = map_read((static_cast<uint64_t>(az) * mg.sy + ay) * mg.sx + ax);
+              st = v > ep.thr_ground ? 2 : (v > ep.thr_unknown ? 1 : 0);
+            }
+          }
+          s_walk[e] = st;
+        }
+        __syncthreads();
+        bool walk_ok = false;
+        if (lane < 6)
+        {
+          walk_ok = true;
+          for (int d = 1; d <= len; d++)
+          {
+            const uint8_t st = s_walk[(lane << 5) + d - 1];
+            if (st == 2)
+              break;  // ground reached through unknown voxels
+            if (st == 0)
+            {
+              walk_ok = false;
+              break;
+            }
+          }
+        }
+        const bool any_walk = __ballot(walk_ok) != 0ull;
+        __syncthreads();
+        if (any_walk)
+        {
+          floating = false;
+          break;
+        }
+      }
       uint32_t n_stack = 1, n_expl = 0, n_touched = 1;  // wave-uniform
       if (lane == 0)
       {

@@ -77,13 +77,17 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_union(const GridParams g, const ClusterParams cp, const StencilRow* __restrict__ rows, const FrameHdr* hdrs,
                                                const unsigned long long* bitmaps, const uint32_t* wprefix_all, VoxelArrays va_all)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t v = BX * blockDim.x + threadIdx.x;
   if (v >= h.V)
     return;
-  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const int dx = h.div_b[0], dy = h.div_b[1], dz = h.div_b[2];
   const uint32_t key = va.key[v];
   const int k = key / (dx * dy);
@@ -178,6 +182,10 @@ template <int SRC>
 __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all, const uint32_t* bmin_all,
                                                  uint32_t bricks_cap)
 {
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
   __shared__ uint32_t s_root[FL_SLOTS];
   __shared__ uint32_t s_cnt[FL_SLOTS];
   __shared__ int s_box[FL_SLOTS][6];
@@ -192,11 +200,11 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
     }
   }
   __syncthreads();
-  const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t v = BX * blockDim.x + threadIdx.x;
   const bool active = v < h.V;
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  uint32_t* labels = labels_all + static_cast<size_t>(blockIdx.y) * g.vox_cap;
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  uint32_t* labels = labels_all + static_cast<size_t>(FRAME) * g.vox_cap;
   uint32_t root = 0xffffffffu;
   int ijk[3] = {0, 0, 0};
   if (active)
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
         root = p;
     }
     else
-      root = bmin_all[static_cast<size_t>(blockIdx.y) * bricks_cap + labels[v]];
+      root = bmin_all[static_cast<size_t>(FRAME) * bricks_cap + labels[v]];
     labels[v] = root;
     const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
     const uint32_t key = va.key[v];
@@ -365,17 +373,21 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
                                                   const FrameHdr* hdrs, const unsigned long long* __restrict__ mapbits, VoxelArrays va_all,
                                                   const uint32_t* labels_all)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t v = BX * blockDim.x + threadIdx.x;
   const bool active = v < h.V;
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const int lane = threadIdx.x & 63;
   uint32_t root = 0;
   int ox = 0, oy = 0, oz = 0;
   bool undecided = false;
   if (active)
   {
-    root = labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v];
+    root = labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v];
     if (!__hip_atomic_load(&va.cclose[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     {
       const float4 p = va.pts[v];
@@ -420,12 +432,16 @@ __global__ __launch_bounds__(256) void k_finalize(const GridParams g, const MapG
                                                   const uint32_t* labels_all, float* __restrict__ vmap, float* __restrict__ vflags, ClusterRec* table_all,
                                                   CandMember* cand_all)
 {
-  FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  FrameHdr& h = hdrs[FRAME];
+  const uint32_t v = BX * blockDim.x + threadIdx.x;
   if (v >= h.V)
     return;
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  const uint32_t root = labels_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + v];
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const uint32_t root = labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v];
   const uint32_t close = va.cclose[root];
   const uint32_t size = va.csize[root];
   const float4 p = va.pts[v];
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(256) void k_finalize(const GridParams g, const MapG
     }
     rec.close = close;
     rec.cand = cand ? 1u : 0u;
-    table_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + slot] = rec;
+    table_all[static_cast<size_t>(FRAME) * g.vox_cap + slot] = rec;
   }
   if (cand)
   {
@@ -474,7 +490,7 @@ __global__ __launch_bounds__(256) void k_finalize(const GridParams g, const MapG
     CandMember cm;
     cm.root = root;
     cm.v = v;
-    cand_all[static_cast<size_t>(blockIdx.y) * g.vox_cap + s] = cm;
+    cand_all[static_cast<size_t>(FRAME) * g.vox_cap + s] = cm;
   }
 }
 

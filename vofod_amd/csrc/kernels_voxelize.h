@@ -26,6 +26,29 @@ __device__ __forceinline__ int f2ord(float f)
 }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
+// Frame/block decode of the 1-D launches that cover n_frames frames with gx blocks each.  With xcd_map the
+// hardware's round-robin block->XCD dealing (block b runs on XCD b % 8: observed, used for speed only) is
+// turned into "every block of frame f runs on XCD f % 8", so a frame's bitmap, prefix array, voxel records and
+// brick words (a few MB) stay resident in that XCD's 4 MB L2 across the whole kernel chain.
+__device__ __forceinline__ bool frame_block(const GridParams& g, uint32_t& frame, uint32_t& bx, uint32_t& gx)
+{
+  const uint32_t L = blockIdx.x;
+  if (!g.xcd_map)
+  {
+    gx = gridDim.x / g.n_frames;
+    frame = L / gx;
+    bx = L - frame * gx;
+    return true;
+  }
+  const uint32_t fpx = (g.n_frames + 7u) >> 3;
+  gx = gridDim.x / (8u * fpx);
+  const uint32_t xcd = L & 7u, idx = L >> 3;
+  const uint32_t local = idx / gx;
+  bx = idx - local * gx;
+  frame = local * 8u + xcd;
+  return frame < g.n_frames;
+}
+
 __device__ __forceinline__ float ldf(const char* base, uint64_t stride, uint32_t i) { return *reinterpret_cast<const float*>(base + static_cast<uint64_t>(i) * stride); }
 
 // CropBox (negative, sensor frame) -> transformPointCloud -> CropBox (positive, world frame):
@@ -89,11 +112,15 @@ __global__ void k_init_hdr(FrameHdr* hdrs)
 // K1-K4a: crop + transform + crop fused with pcl::getMinMax3D (voxel_grid_weighted.cpp:58).
 __global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridParams g, FrameHdr* hdrs)
 {
-  const FrameArgs& a = args[blockIdx.y];
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameArgs& a = args[FRAME];
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
   uint32_t cnt = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+  for (uint32_t i = BX * blockDim.x + threadIdx.x; i < a.n; i += GX * blockDim.x)
   {
     float q[3];
     if (!fetch_point(a, g, i, q))
@@ -145,7 +172,7 @@ __global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridP
     }
     if (tot)
     {
-      FrameHdr& h = hdrs[blockIdx.y];
+      FrameHdr& h = hdrs[FRAME];
       atomicAdd(&h.n_in, tot);
 #pragma unroll
       for (int c = 0; c < 3; c++)
@@ -232,14 +259,18 @@ __device__ __forceinline__ bool run_heads(uint32_t w, int lane, int& end)
 // when the bits are already set.
 __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, unsigned long long* bitmaps)
 {
-  const FrameArgs& a = args[blockIdx.y];
-  const FrameHdr& h = hdrs[blockIdx.y];
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameArgs& a = args[FRAME];
+  const FrameHdr& h = hdrs[FRAME];
   if (h.n_in == 0)
     return;
-  unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   const int lane = threadIdx.x & 63;
   const uint32_t n_round = (a.n + 63u) & ~63u;  // whole waves stay in the loop: the shuffles need every lane
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x)
+  for (uint32_t i = BX * blockDim.x + threadIdx.x; i < n_round; i += GX * blockDim.x)
   {
     float q[3];
     uint32_t word = 0xffffffffu;
@@ -302,11 +333,15 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* ld
 
 __global__ __launch_bounds__(256) void k_scan_a(const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps, uint32_t* blocksums, uint32_t nblk_cap)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
-  const uint32_t w0 = blockIdx.x * SCAN_WPB + threadIdx.x * SCAN_WPT;
-  if (blockIdx.x * SCAN_WPB >= h.n_words)
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
     return;
-  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t w0 = BX * SCAN_WPB + threadIdx.x * SCAN_WPT;
+  if (BX * SCAN_WPB >= h.n_words)
+    return;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   uint32_t c = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_WPT; k++)
@@ -316,7 +351,7 @@ __global__ __launch_bounds__(256) void k_scan_a(const GridParams g, const FrameH
   uint32_t total;
   block_excl_scan_256(c, lds4, &total);
   if (threadIdx.x == 0)
-    blocksums[static_cast<size_t>(blockIdx.y) * nblk_cap + blockIdx.x] = total;
+    blocksums[static_cast<size_t>(FRAME) * nblk_cap + BX] = total;
 }
 
 // one 1024-thread block per frame: exclusive scan of the block sums, total -> hdr.V
@@ -392,13 +427,17 @@ __device__ __forceinline__ VoxelArrays frame_voxels(const VoxelArrays& base, uin
 __global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
                                               uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all)
 {
-  const FrameHdr& h = hdrs[blockIdx.y];
-  if (blockIdx.x * SCAN_WPB >= h.n_words || h.V == 0)
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
     return;
-  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
-  const uint32_t wbase = blockIdx.x * SCAN_WPB;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  if (BX * SCAN_WPB >= h.n_words || h.V == 0)
+    return;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const uint32_t wbase = BX * SCAN_WPB;
   const uint32_t w0 = wbase + threadIdx.x * SCAN_WPT;
   __shared__ unsigned long long s_words[SCAN_WPB];
   __shared__ uint32_t s_start[256 + 1];
@@ -414,7 +453,7 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr
   }
   uint32_t total;
   const uint32_t excl = block_excl_scan_256(c, lds4, &total);
-  const uint32_t base = blocksums[static_cast<size_t>(blockIdx.y) * nblk_cap + blockIdx.x];
+  const uint32_t base = blocksums[static_cast<size_t>(FRAME) * nblk_cap + BX];
   s_start[threadIdx.x] = excl;
   if (threadIdx.x == 0)
     s_start[256] = total;
@@ -489,16 +528,20 @@ __device__ __forceinline__ uint32_t rank_of(const unsigned long long* bm, const 
 __global__ __launch_bounds__(256) void k_count(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps,
                                                const uint32_t* wprefix_all, VoxelArrays va_all, uint32_t* pt_rank, uint32_t pt_cap)
 {
-  const FrameArgs& a = args[blockIdx.y];
-  const FrameHdr& h = hdrs[blockIdx.y];
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameArgs& a = args[FRAME];
+  const FrameHdr& h = hdrs[FRAME];
   if (h.n_in == 0 || h.V == 0)
     return;
-  const unsigned long long* bm = bitmaps + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(blockIdx.y) * (g.words_cap + 2);
-  const VoxelArrays va = frame_voxels(va_all, blockIdx.y, g.vox_cap);
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const int lane = threadIdx.x & 63;
   const uint32_t n_round = (a.n + 63u) & ~63u;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x)
+  for (uint32_t i = BX * blockDim.x + threadIdx.x; i < n_round; i += GX * blockDim.x)
   {
     float q[3];
     uint32_t key = 0xffffffffu;
@@ -516,7 +559,7 @@ __global__ __launch_bounds__(256) void k_count(const FrameArgs* args, const Grid
     if (head && key != 0xffffffffu)
       atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[r].w), static_cast<uint32_t>(end - lane));
     if (pt_rank && i < a.n)
-      pt_rank[static_cast<size_t>(blockIdx.y) * pt_cap + i] = r;
+      pt_rank[static_cast<size_t>(FRAME) * pt_cap + i] = r;
   }
 }
 

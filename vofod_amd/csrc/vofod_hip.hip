@@ -11,12 +11,14 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "common.h"
 #include "host_tail.h"
+#include "thread_pool.h"
 #include "kernels_brick.h"
 #include "kernels_classify.h"
 #include "kernels_cluster.h"
@@ -49,10 +51,14 @@ static_assert(sizeof(FrameHdr) <= 128, "FrameHdr grew past its slot");
 
 __global__ void k_pack(const GridParams g, const FrameHdr* hdrs, const ClusterRec* table_all, const CandMember* cand_all, VoxelArrays va_all, PackedFrame* out)
 {
-  const uint32_t f = blockIdx.y;
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const uint32_t f = FRAME;
   const FrameHdr h = hdrs[f];
   PackedFrame& o = out[f];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = BX * blockDim.x + threadIdx.x;
   if (t == 0)
     o.hdr = h;
   if (t < min(h.C, SPEC_C))
@@ -281,6 +287,7 @@ struct vofod_handle
 
   Workspace ws, aux, sepws;
   ExploreBufs explore;
+  std::unique_ptr<vt::Pool> pool;
   struct ClusterTables
   {
     bool valid = false;
@@ -448,7 +455,18 @@ bool build_brick_tables(const float leaf[3], float tol, float cmax, std::vector<
         }
         if (!any)
           continue;
-        offs.push_back(BrickOff{static_cast<int8_t>(bx), static_cast<int8_t>(by), static_cast<int8_t>(bz), static_cast<uint8_t>(any_amb)});
+        BrickOff bo{};
+        bo.dx = static_cast<int8_t>(bx);
+        bo.dy = static_cast<int8_t>(by);
+        bo.dz = static_cast<int8_t>(bz);
+        bo.has_amb = static_cast<uint8_t>(any_amb);
+        for (int p = 0; p < 64; p++)
+        {
+          if (ms[p] | ma[p])
+            bo.ua |= 1ull << p;
+          bo.ub |= ms[p] | ma[p];
+        }
+        offs.push_back(bo);
         sure.insert(sure.end(), ms, ms + 64);
         amb.insert(amb.end(), ma, ma + 64);
       }
@@ -511,6 +529,8 @@ void fill_grid_params(vofod_handle* h, GridParams& g, const float leaf[3], bool 
   g.align = align;
   g.words_cap = ws.words_cap;
   g.vox_cap = ws.vox_cap;
+  g.n_frames = 1;
+  g.xcd_map = 0;
 }
 
 int ensure_boxstage(vofod_handle* h, size_t n)
@@ -635,23 +655,35 @@ int stage_cloud(vofod_handle* h, Workspace& ws, uint32_t f, const void* x, const
   return VOFOD_OK;
 }
 
-// kernel chain K1-K6 over frames [0,n): bbox -> lattice -> occupancy bitmap -> ranks -> weighted cloud
-int launch_voxelize(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank, bool two_phase)
+// 1-D grid of a per-frame kernel: n_frames x gx blocks (see frame_block in kernels_voxelize.h)
+inline dim3 fgrid(const GridParams& g, uint32_t gx)
 {
+  if (!g.xcd_map)
+    return dim3(g.n_frames * gx);
+  return dim3(8u * ((g.n_frames + 7u) / 8u) * gx);
+}
+
+// kernel chain K1-K6 over frames [0,n): bbox -> lattice -> occupancy bitmap -> ranks -> weighted cloud
+int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank, bool two_phase)
+{
+  g.n_frames = n;
+  // measured on MI355X (32 frames, 0.25 m): the XCD-aware mapping is 5-9 % slower than plain dealing, so it is opt-in
+  static const bool xcd_on = std::getenv("VOFOD_XCD_MAP") && std::atoi(std::getenv("VOFOD_XCD_MAP")) == 1;
+  g.xcd_map = (n >= 8 && xcd_on) ? 1u : 0u;
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs);
   const uint32_t gb = std::max(1u, std::min((max_pts + 2047u) / 2048u, 1024u));  // 8 points per thread: few header atomics
-  KLAUNCH(h, k_bbox, dim3(gb, n), dim3(256), ws.d_args, g, ws.d_hdrs);
+  KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
   KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
   HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
-  KLAUNCH(h, k_setbits, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
-  KLAUNCH(h, k_scan_a, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+  KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
+  KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
-  KLAUNCH(h, k_count, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
+  KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -660,11 +692,11 @@ int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, ui
 {
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
-  KLAUNCH(h, k_setbits, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
-  KLAUNCH(h, k_scan_a, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+  KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
+  KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, dim3(ws.nblk_cap, n), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
-  KLAUNCH(h, k_count, dim3(gx, n), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va);
+  KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
@@ -727,20 +759,25 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
   {
     BrickParams bp = ct->bp;
     bp.bricks_cap = ws.bricks_cap;
-    KLAUNCH(h, k_brick_set, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
-    static const int blanes = std::getenv("VOFOD_BRICK_LANES") ? std::atoi(std::getenv("VOFOD_BRICK_LANES")) : 1;
-    if (blanes == 4)
-      KLAUNCH(h, k_brick_union<4>, dim3(gv * 4, n), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
+    KLAUNCH(h, k_brick_set, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
+    static const int bmode = std::getenv("VOFOD_BRICK_MODE") ? std::atoi(std::getenv("VOFOD_BRICK_MODE")) : 1;  // 2 = masks + batched hooking: measured slower
+    if (bmode == 2 && bp.n_off <= 64)
+    {
+      // ws.d_table is free until k_finalize: it holds the per-brick connectivity masks in between
+      unsigned long long* conn = reinterpret_cast<unsigned long long*>(ws.d_table);
+      KLAUNCH(h, k_brick_conn, fgrid(g, gv * CONN_LANES), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba, conn);
+      KLAUNCH(h, k_brick_link, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ws.d_hdrs, ws.ba, conn);
+    }
     else
-      KLAUNCH(h, k_brick_union<1>, dim3(gv, n), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
-    KLAUNCH(h, k_brick_min, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba, ws.d_labels);
-    KLAUNCH(h, k_flatten<1>, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba.bmin, ws.bricks_cap);
-    KLAUNCH(h, k_brick_clear, dim3(gv, n), dim3(256), g, bp, ws.d_hdrs, ws.ba);
+      KLAUNCH(h, k_brick_union<1>, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
+    KLAUNCH(h, k_brick_min, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba, ws.d_labels);
+    KLAUNCH(h, k_flatten<1>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba.bmin, ws.bricks_cap);
+    KLAUNCH(h, k_brick_clear, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.ba);
   }
   else
   {
-    KLAUNCH(h, k_union<2>, dim3(gv, n), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
-    KLAUNCH(h, k_flatten<0>, dim3(gv, n), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, static_cast<const uint32_t*>(nullptr), 0u);
+    KLAUNCH(h, k_union<2>, fgrid(g, gv), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
+    KLAUNCH(h, k_flatten<0>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, static_cast<const uint32_t*>(nullptr), 0u);
   }
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
@@ -815,7 +852,7 @@ int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
 }
 
 // Fallback of k_explore for one frame: the same flood fills and sums on read-back boxes of the map.
-int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, std::map<uint32_t, std::vector<vt::Member>>& by_root, const std::vector<int>& job_of,
+int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, const vt::MemberIndex& by_root, const std::vector<int>& job_of,
                        const std::vector<vc::ExploreJob>& jobs, std::vector<vc::ExploreResult>& results, bool no_update, float thr_frontiers, float thr_new)
 {
   const vofod_dyn_params& dp = h->dp;
@@ -831,7 +868,7 @@ int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, std::map<u
     if (ji < 0)
       continue;
     const vc::ExploreJob& job = jobs[ji];
-    const std::vector<vt::Member>& mem = by_root[cl[ci].rec.root];
+    const vt::MemberSpan mem = by_root.of(cl[ci].rec.root);
     const int R = job.R;
     int lo[3], hi[3];
     for (int a = 0; a < 3; a++)
@@ -893,7 +930,7 @@ int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, std::map<u
     if (ji < 0 || !results[ji].floating)
       continue;
     const vc::ExploreJob& job = jobs[ji];
-    const std::vector<vt::Member>& mem = by_root[cl[ci].rec.root];
+    const vt::MemberSpan mem = by_root.of(cl[ci].rec.root);
     int mn[3] = {job.box_lo[0], job.box_lo[1], job.box_lo[2]}, mx[3] = {job.box_hi[0], job.box_hi[1], job.box_hi[2]};
     vt::Box sub;
     const int r = read_box(h, h->d_map, mn, mx, sub);
@@ -952,6 +989,8 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   const bool no_update = flags & VOFOD_SCAN_NO_MAP_UPDATE;
   int ret = VOFOD_OK;
   auto t0 = clk::now();
+  static const bool trace = std::getenv("VOFOD_TRACE") != nullptr;
+  double tr_launch = 0, tr_sync1 = 0, tr_prep = 0, tr_explore = 0, tr_a = 0, tr_b = 0, tr_c = 0;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (dbg)
     for (auto& e : ev)
@@ -1007,7 +1046,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   }
   CloseParams cpar{h->closetab.n_rows, thr_new};
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
-  KLAUNCH(h, k_closefar, dim3(gv, n), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
+  KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
   if (dbg)
     HIPCHK(hipEventRecord(ev[3], h->stream));
 
@@ -1018,12 +1057,14 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   up.min_points = dp.classification__min_points;
   up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
   up.no_update = no_update;
-  KLAUNCH(h, k_finalize, dim3(gv, n), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand);
-  KLAUNCH(h, k_pack, dim3((std::max(SPEC_C, SPEC_M) + 255) / 256, n), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
+  KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand);
+  KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
   HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
   if (dbg)
     HIPCHK(hipEventRecord(ev[4], h->stream));
+  tr_launch = ms_since(t0);
   HIPCHK(hipStreamSynchronize(h->stream));
+  tr_sync1 = ms_since(t0);
   if (!no_update)
     h->mapbits_valid = false;
 
@@ -1062,7 +1103,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   struct FrameTail
   {
     std::vector<HostCluster> cl;
-    std::map<uint32_t, std::vector<vt::Member>> by_root;
+    vt::MemberIndex by_root;
     std::vector<int> job_of;  // per cluster: index into jobs or -1
     bool host_fallback = false;
   };
@@ -1071,31 +1112,39 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   std::vector<uint32_t> job_begin(n + 1, 0);
   std::vector<int> job_members;
   const bool latches = h->background_pts_sufficient && h->sure_background_sufficient;
+  // phase A (serial): frames whose tables overflowed the speculative read-back fetch the rest
+  std::vector<std::vector<ClusterRec>> recs_big(n);
+  std::vector<std::vector<CandMemberX>> members_big(n);
   for (uint32_t f = 0; f < n; f++)
   {
-    FrameTail& T = tails[f];
-    const PackedFrame& pf = ws.h_packed[f];
-    const FrameHdr& hdr = pf.hdr;
+    const FrameHdr& hdr = ws.h_packed[f].hdr;
     if (hdr.status != VOFOD_OK)
       ret = hdr.status;
-    std::vector<ClusterRec> recs(hdr.C);
-    if (hdr.C <= SPEC_C)
-      std::copy(pf.table, pf.table + hdr.C, recs.begin());
-    else
-      HIPCHK(hipMemcpy(recs.data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
-    const CandMemberX* members = pf.members;
-    std::vector<CandMemberX> members_big;
+    if (hdr.C > SPEC_C)
+    {
+      recs_big[f].resize(hdr.C);
+      HIPCHK(hipMemcpy(recs_big[f].data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
+    }
     if (hdr.n_cand > SPEC_M)
     {
-      members_big.resize(hdr.n_cand);
+      members_big[f].resize(hdr.n_cand);
       CandMemberX* d_tmp = nullptr;
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_tmp), sizeof(CandMemberX) * hdr.n_cand));
       KLAUNCH(h, k_gather_members, dim3((hdr.n_cand + 255) / 256), dim3(256), g, f, hdr.n_cand, ws.d_cand, ws.va, d_tmp);
-      HIPCHK(hipMemcpyAsync(members_big.data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(members_big[f].data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       (void)hipFree(d_tmp);
-      members = members_big.data();
     }
+  }
+  // phase B (parallel over frames): canonical order, member index, boxes and gates, the frame's explore jobs
+  std::vector<std::vector<vc::ExploreJob>> jobs_f(n);
+  std::vector<std::vector<int>> members_f(n);
+  auto prep_frame = [&](uint32_t f) {
+    FrameTail& T = tails[f];
+    const PackedFrame& pf = ws.h_packed[f];
+    const FrameHdr& hdr = pf.hdr;
+    const ClusterRec* recs = hdr.C > SPEC_C ? recs_big[f].data() : pf.table;
+    const CandMemberX* members = hdr.n_cand > SPEC_M ? members_big[f].data() : pf.members;
     // canonical order: size desc, smallest member asc
     T.cl.resize(hdr.C);
     for (uint32_t c = 0; c < hdr.C; c++)
@@ -1105,17 +1154,20 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
         return a.rec.size > b.rec.size;
       return a.rec.root < b.rec.root;
     });
-    for (uint32_t i = 0; i < hdr.n_cand; i++)
     {
-      const CandMemberX& m = members[i];
-      T.by_root[m.root].push_back(vt::Member{m.v, {m.x, m.y, m.z}, m.count});
+      std::vector<std::pair<uint64_t, vt::Member>> tmp(hdr.n_cand);
+      for (uint32_t i = 0; i < hdr.n_cand; i++)
+      {
+        const CandMemberX& m = members[i];
+        tmp[i] = {(static_cast<uint64_t>(m.root) << 32) | m.v, vt::Member{m.v, {m.x, m.y, m.z}, m.count}};
+      }
+      T.by_root.build(tmp);
     }
-    for (auto& kv : T.by_root)
-      std::sort(kv.second.begin(), kv.second.end(), [](const vt::Member& a, const vt::Member& b) { return a.v < b.v; });
     T.job_of.assign(hdr.C, -1);
     const float* tf = tfs + 12 * f;
     const float tpos[3] = {tf[3], tf[7], tf[11]};
-    job_begin[f] = static_cast<uint32_t>(jobs.size());
+    std::vector<vc::ExploreJob>& jl = jobs_f[f];
+    std::vector<int>& ml = members_f[f];
     // classify_cluster :1648-1690: boxes and gates
     for (uint32_t ci = 0; ci < hdr.C; ci++)
     {
@@ -1125,7 +1177,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       c.cclass = VOFOD_CLASS_INVALID;
       if (!c.rec.cand)
         continue;  // fails min_points or cannot pass max_size (device-side gate)
-      const std::vector<vt::Member>& mem = T.by_root[c.rec.root];
+      const vt::MemberSpan mem = T.by_root.of(c.rec.root);
       c.boxes = vt::boxes_of(mem);
       c.evaluated = true;
       if (static_cast<int>(mem.size()) < dp.classification__min_points)
@@ -1150,13 +1202,13 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       vc::ExploreJob job{};
       job.frame = f;
       job.n_members = static_cast<uint32_t>(mem.size());
-      job.member_off = static_cast<uint32_t>(job_members.size() / 3);
+      job.member_off = static_cast<uint32_t>(ml.size() / 3);  // rebased when the frames are concatenated
       job.R = static_cast<int>((c.obb_size + dp.classification__max_explore_distance) / sp.voxel_size);  // :1696
       for (const vt::Member& m : mem)
       {
         int o[3];
         h->hg.coordToIdx(m.p, o);
-        job_members.insert(job_members.end(), o, o + 3);
+        ml.insert(ml.end(), o, o + 3);
       }
       int mn[3], mx[3];  // getSubmapCopy(aabb, inflate 2) voxel_map.cpp:550-559
       h->hg.coordToIdx(c.boxes.aabb_min, mn);
@@ -1166,17 +1218,34 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
         job.box_lo[a] = std::clamp(mn[a] - 2, 0, h->hg.s[a] - 1);
         job.box_hi[a] = std::clamp(mx[a] + 2, 0, h->hg.s[a] - 1);
       }
-      job.result_slot = static_cast<uint32_t>(jobs.size());
       if (job.R > vc::EX_MAX_R || job.R < 0)
         T.host_fallback = true;
-      T.job_of[ci] = static_cast<int>(jobs.size());
-      jobs.push_back(job);
+      T.job_of[ci] = static_cast<int>(jl.size());  // rebased below
+      jl.push_back(job);
     }
-    if (jobs.size() - job_begin[f] > vc::EX_MAX_JOBS)
+    if (jl.size() > vc::EX_MAX_JOBS)
       T.host_fallback = true;
+  };
+  h->pool->parallel_for(n, prep_frame);
+  // phase C (serial): concatenate the frames' job lists in frame order
+  for (uint32_t f = 0; f < n; f++)
+  {
+    job_begin[f] = static_cast<uint32_t>(jobs.size());
+    const uint32_t jbase = static_cast<uint32_t>(jobs.size()), mbase = static_cast<uint32_t>(job_members.size() / 3);
+    for (vc::ExploreJob j : jobs_f[f])
+    {
+      j.member_off += mbase;
+      j.result_slot = static_cast<uint32_t>(jobs.size());
+      jobs.push_back(j);
+    }
+    job_members.insert(job_members.end(), members_f[f].begin(), members_f[f].end());
+    for (int& ji : tails[f].job_of)
+      if (ji >= 0)
+        ji += static_cast<int>(jbase);
   }
   job_begin[n] = static_cast<uint32_t>(jobs.size());
 
+  tr_prep = ms_since(t0);
   std::vector<vc::ExploreResult> results(jobs.size());
   static const bool force_host = std::getenv("VOFOD_EXPLORE") && std::strcmp(std::getenv("VOFOD_EXPLORE"), "host") == 0;  // tests exercise the fallback
   bool any_host = force_host;
@@ -1206,6 +1275,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       h->mapbits_valid = false;
   }
 
+  tr_explore = ms_since(t0);
   size_t total = 0;
   for (uint32_t f = 0; f < n; f++)
   {
@@ -1235,7 +1305,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       HostCluster& c = T.cl[ci];
       if (c.rec.close || c.cclass != VOFOD_CLASS_MAV)
         continue;
-      const std::vector<vt::Member>& mem = T.by_root[c.rec.root];
+      const vt::MemberSpan mem = T.by_root.of(c.rec.root);
       vofod_detection det{};
       const float d[3] = {tpos[0] - c.boxes.obb_center[0], tpos[1] - c.boxes.obb_center[1], tpos[2] - c.boxes.obb_center[2]};
       const double det_dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -1307,6 +1377,20 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
       d.stage_ms[4] = ms_since(t_tail);
       d.stage_ms[5] = ms_since(t0);
     }
+  }
+  if (trace)
+  {
+    size_t sumC = 0, sumCand = 0, sumEval = 0;
+    for (uint32_t f = 0; f < n; f++)
+    {
+      sumC += ws.h_packed[f].hdr.C;
+      sumCand += ws.h_packed[f].hdr.n_cand;
+      for (const auto& c : tails[f].cl)
+        sumEval += c.evaluated;
+    }
+    std::fprintf(stderr, "[vofod trace] n=%u launch %.3f sync1 %.3f prep %.3f explore %.3f end %.3f ms jobs %zu C %zu cand_members %zu evaluated %zu | sort %.3f gates %.3f\n", n, tr_launch, tr_sync1,
+                 tr_prep, tr_explore, ms_since(t0), jobs.size(), sumC, sumCand, sumEval, tr_a, tr_b);
+    (void)tr_c;
   }
   *n_out = total;
   if (total > cap)
