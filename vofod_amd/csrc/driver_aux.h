@@ -263,17 +263,13 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
   int r = ensure_mapbits(h, thr_new);
   if (r != VOFOD_OK)
     return r;
-  const uint32_t n_words = static_cast<uint32_t>((h->mg.n + 63) >> 6);
-  if ((r = sep_ensure_words(h, n_words)) != VOFOD_OK)
+  const uint32_t ncol = static_cast<uint32_t>(h->mg.sx) * h->mg.sy;
+  if ((r = sep_ensure_words(h, ncol + 2)) != VOFOD_OK)
     return r;
-  if ((r = sep_ensure_pts(h, 1 << 16)) != VOFOD_OK)
+  if ((r = sep_ensure_pts(h, std::max<size_t>(1 << 16, ncol))) != VOFOD_OK)  // also sizes the scan's block sums
     return r;
-  KLAUNCH(h, vr::k_transpose_bits, dim3(256 * 8), dim3(256), h->mg, h->d_mapbits, s.d_tbits);
-  KLAUNCH(h, vr::k_popc_words, dim3((n_words + 255) / 256), dim3(256), s.d_tbits, n_words, s.d_tpop);
-  if (s.pts_cap / vr::GS_EPB + 1024 < n_words / vr::GS_EPB + 2)
-    if ((r = sep_ensure_pts(h, static_cast<size_t>(n_words))) != VOFOD_OK)
-      return r;
-  if ((r = gscan(h, s.d_tpop, n_words, s.d_tprefix, s.d_bsum, s.d_small)) != VOFOD_OK)
+  KLAUNCH(h, vr::k_col_count, dim3((ncol + 255) / 256), dim3(256), h->mg, h->d_mapbits, s.d_tpop);
+  if ((r = gscan(h, s.d_tpop, ncol, s.d_tprefix, s.d_bsum, s.d_small)) != VOFOD_OK)
     return r;
   HIPCHK(hipMemcpyAsync(s.h_small, s.d_small, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -283,7 +279,7 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
     return VOFOD_ERR_EMPTY;  // :1155-1159
   if ((r = sep_ensure_pts(h, P)) != VOFOD_OK)
     return r;
-  KLAUNCH(h, vr::k_emit_vpc, dim3((n_words + 255) / 256), dim3(256), h->mg, h->d_map, s.d_tbits, s.d_tprefix, n_words, thr_sure, s.d_px, s.d_py, s.d_pz, s.d_pi, s.d_sure);
+  KLAUNCH(h, vr::k_col_emit, dim3((ncol + 255) / 256), dim3(256), h->mg, h->d_map, h->d_mapbits, s.d_tprefix, thr_sure, s.d_px, s.d_py, s.d_pz, s.d_pi, s.d_sure);
 
   // K6': VoxelGridCounted with leaf lsz on the index cloud (:1162-1167)
   vofod_cloud_view view{};
@@ -493,6 +489,10 @@ void vofod_destroy(vofod_handle* h)
         (void)hipFree(p);
   if (h->h_counter)
     (void)hipHostFree(h->h_counter);
+  if (h->d_bgcount)
+    (void)hipFree(h->d_bgcount);
+  if (h->h_bgcount)
+    (void)hipHostFree(h->h_bgcount);
   if (h->sep.h_small)
     (void)hipHostFree(h->sep.h_small);
   if (h->stream)
@@ -562,6 +562,8 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   CREATE_CHK(hipMemset(h->d_mapbits, 0, ((M + 63) / 64 + 2) * sizeof(unsigned long long)));
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_counter), 8 * sizeof(unsigned long long)));
   CREATE_CHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counter), 8 * sizeof(unsigned long long)));
+  CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_bgcount), 8 * MB_SLOTS * sizeof(unsigned long long)));
+  CREATE_CHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_bgcount), 8 * MB_SLOTS * sizeof(unsigned long long)));
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_rows), MAX_STENCIL_ROWS * sizeof(StencilRow)));
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_crows), MAX_STENCIL_ROWS * sizeof(CloseRow)));
   // sensor

@@ -75,20 +75,35 @@ __global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const Bri
   (void)GX;
   FrameHdr& h = hdrs[FRAME];
   const uint32_t v = BX * blockDim.x + threadIdx.x;
-  if (v >= h.V)
-    return;
+  const bool active = v < h.V;
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
-  int i, j, k, bit;
-  key_to_ijk(h, va.key[v], i, j, k);
-  const uint32_t b = brick_of(h, i, j, k, bit);
-  const unsigned long long old = atomicOr(&ba.bricks[b], 1ull << bit);
-  if (old == 0ull)
+  uint32_t b = 0;
+  bool first = false;
+  if (active)
   {
-    const uint32_t slot = atomicAdd(&h.n_bricks, 1u);
-    ba.blist[slot] = b;
-    ba.bparent[b] = b;
-    ba.bmin[b] = 0xffffffffu;
+    int i, j, k, bit;
+    key_to_ijk(h, va.key[v], i, j, k);
+    b = brick_of(h, i, j, k, bit);
+    first = atomicOr(&ba.bricks[b], 1ull << bit) == 0ull;
+  }
+  // list append: one counter atomic per wave instead of one per new brick (same-address atomics serialise)
+  const unsigned long long m = __ballot(first);
+  if (m)
+  {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&h.n_bricks, static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, leader);
+    if (first)
+    {
+      const uint32_t slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      ba.blist[slot] = b;
+      ba.bparent[b] = b;
+      ba.bmin[b] = 0xffffffffu;
+    }
   }
 }
 

@@ -310,38 +310,74 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
 // (voxel_map.cpp:216-222, called per scan at vofod_nodelet.cpp:715).  Streaming, HBM-bound:
 // 4 B read per voxel, 1 bit written.  Each wave turns 64 consecutive voxels into one bitmap word
 // with a ballot; eight independent coalesced loads are kept in flight per lane.
-constexpr int MB_UNROLL = 8;
+// Each lane loads 16 bytes (4 voxels), turns them into a nibble, and 16 lanes OR their nibbles into one
+// 64-bit word with four xor-shuffles; four independent float4 loads are kept in flight per lane.
+constexpr int MB_UNROLL = 4;
+constexpr int MB_SLOTS = 64;  // partial counters, 64 B apart
 __global__ __launch_bounds__(256) void k_mapbits(const float* __restrict__ map, uint64_t n, float threshold, unsigned long long* __restrict__ bits,
                                                  unsigned long long* __restrict__ count)
 {
+  const uint64_t n4 = n >> 2;  // whole float4 groups; the tail is handled by the last lanes scalar-wise
   const uint64_t n_words = (n + 63) >> 6;
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t nthreads = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const float4* map4 = reinterpret_cast<const float4*>(map);
   unsigned long long local = 0;
-  for (uint64_t w = wave * MB_UNROLL; w < n_words; w += n_waves * MB_UNROLL)
+  // group index gi covers voxels [4*gi, 4*gi+4); a wave covers 256 consecutive voxels = 4 words per load
+  const uint64_t n_groups = (n + 3) >> 2;
+  const uint64_t n_groups_round = (n_groups + 63) & ~63ull;
+  for (uint64_t g0 = tid; g0 < n_groups_round; g0 += nthreads * MB_UNROLL)
   {
-    float m[MB_UNROLL];
+    float4 v[MB_UNROLL];
 #pragma unroll
     for (int u = 0; u < MB_UNROLL; u++)
     {
-      const uint64_t idx = (w + u) * 64 + lane;
-      m[u] = idx < n ? map[idx] : -INFINITY;
+      const uint64_t gi = g0 + static_cast<uint64_t>(u) * nthreads;
+      if (gi < n4)
+        v[u] = map4[gi];
+      else
+      {
+        const uint64_t e = gi << 2;
+        v[u].x = e + 0 < n ? map[e + 0] : -INFINITY;
+        v[u].y = e + 1 < n ? map[e + 1] : -INFINITY;
+        v[u].z = e + 2 < n ? map[e + 2] : -INFINITY;
+        v[u].w = e + 3 < n ? map[e + 3] : -INFINITY;
+      }
     }
 #pragma unroll
     for (int u = 0; u < MB_UNROLL; u++)
     {
-      const unsigned long long b = __ballot(m[u] > threshold);
-      if (w + u < n_words)
+      const uint64_t gi = g0 + static_cast<uint64_t>(u) * nthreads;
+      const unsigned nib = (v[u].x > threshold ? 1u : 0u) | (v[u].y > threshold ? 2u : 0u) | (v[u].z > threshold ? 4u : 0u) | (v[u].w > threshold ? 8u : 0u);
+      unsigned long long w = static_cast<unsigned long long>(nib) << ((lane & 15u) * 4u);
+      w |= __shfl_xor(w, 1);
+      w |= __shfl_xor(w, 2);
+      w |= __shfl_xor(w, 4);
+      w |= __shfl_xor(w, 8);
+      const uint64_t wi = gi >> 4;
+      if ((lane & 15u) == 0 && wi < n_words)
       {
-        if (lane == 0)
-          bits[w + u] = b;
-        local += __popcll(b);
+        bits[wi] = w;
+        local += __popcll(w);
       }
     }
   }
-  if (lane == 0 && local)
-    atomicAdd(count, local);
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1)
+    local += __shfl_xor(local, s);
+  // one atomic per block, spread over MB_SLOTS counters on separate cache lines: thousands of atomics on ONE address
+  // serialise at ~13 ns each and were measured to cost more than the whole sweep (tools/ubench/mapbits.hip)
+  __shared__ unsigned long long s_red[4];
+  if (lane == 0)
+    s_red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (t)
+      atomicAdd(&count[(blockIdx.x % MB_SLOTS) * 8], t);
+  }
 }
 
 // K9: hasCloseTo (voxel_map.cpp:376-400) for every voxel against the occupancy image.

@@ -32,13 +32,13 @@ __global__ __launch_bounds__(256) void k_raycast(const RayParams rp, const MapGe
                                                  const float* __restrict__ lut_dirs, const float* __restrict__ lut_offs, const uint8_t* __restrict__ mask,
                                                  float* __restrict__ ray, uint32_t* __restrict__ any_hit)
 {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rp.n)
-    return;
+  const uint32_t idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  bool alive = idx_raw < rp.n;
+  const uint32_t idx = alive ? idx_raw : 0u;
   const float inten = *reinterpret_cast<const float*>(intensity + static_cast<uint64_t>(idx) * stride);
   const uint32_t rng = *reinterpret_cast<const uint32_t*>(range + static_cast<uint64_t>(idx) * stride);
   if (inten < rp.min_intensity || (!mask[idx] && rng == 0))  // vofod_nodelet.cpp:1449
-    return;
+    alive = false;
   float dir[3], start[3];
 #pragma unroll
   for (int r = 0; r < 3; r++)
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_raycast(const RayParams rp, const MapGe
   int cur[3] = {c2i(start[0], mg.off[0], mg.vs_inv), c2i(start[1], mg.off[1], mg.vs_inv), c2i(start[2], mg.off[2], mg.vs_inv)};
   const int lim[3] = {mg.sx, mg.sy, mg.sz};
   if (cur[0] < 0 || cur[0] >= lim[0] || cur[1] < 0 || cur[1] >= lim[1] || cur[2] < 0 || cur[2] >= lim[2])  // :1482
-    return;
+    alive = false;
   // forEachRay voxel_map.cpp:229-263
   const float half = mg.vs / 2.0f;
   float tdelta[3], tmax[3];
@@ -68,41 +68,66 @@ __global__ __launch_bounds__(256) void k_raycast(const RayParams rp, const MapGe
     tmax[a] = __fdiv_rn(__fadd_rn(half, __fmul_rn(static_cast<float>(step[a]), ctr_offset)), absdir);
     last[a] = step[a] > 0 ? lim[a] - 1 : 0;
   }
+  // Neighbouring lanes are neighbouring azimuth columns of one ring: their walks visit almost the same voxels in
+  // almost the same order, so per DDA step the wave merges runs of lanes that sit in the same voxel (segmented
+  // shuffle sum) and issues one float atomic per run instead of one per lane.  The loop is kept wave-uniform.
   float prev = 0.0f;
   bool any = false;
-  while (prev < length)
+  bool active = alive && prev < length;
+  const int lane = threadIdx.x & 63;
+  while (__ballot(active))
   {
-    int i = 0;
-    if (tmax[1] < tmax[i])
-      i = 1;
-    if (tmax[2] < tmax[i])
-      i = 2;
-    const float dist = i == 0 ? tmax[0] : (i == 1 ? tmax[1] : tmax[2]);
-    const float dd = __fsub_rn(fminf(dist, length), prev);
-    if (dd != 0.0f)
+    uint32_t key = 0xffffffffu;
+    float dd = 0.0f;
+    if (active)
     {
-      unsafeAtomicAdd(&ray[(static_cast<uint64_t>(cur[2]) * mg.sy + cur[1]) * mg.sx + cur[0]], dd);
+      int i = 0;
+      if (tmax[1] < tmax[i])
+        i = 1;
+      if (tmax[2] < tmax[i])
+        i = 2;
+      const float dist = i == 0 ? tmax[0] : (i == 1 ? tmax[1] : tmax[2]);
+      dd = __fsub_rn(fminf(dist, length), prev);
+      if (dd != 0.0f)
+        key = static_cast<uint32_t>((static_cast<uint64_t>(cur[2]) * mg.sy + cur[1]) * mg.sx + cur[0]);
+      prev = dist;
+      const int ci = i == 0 ? cur[0] : (i == 1 ? cur[1] : cur[2]);
+      const int li = i == 0 ? last[0] : (i == 1 ? last[1] : last[2]);
+      if (ci == li)
+        active = false;
+      else
+      {
+        if (i == 0)
+        {
+          cur[0] += step[0];
+          tmax[0] = __fadd_rn(tmax[0], tdelta[0]);
+        }
+        else if (i == 1)
+        {
+          cur[1] += step[1];
+          tmax[1] = __fadd_rn(tmax[1], tdelta[1]);
+        }
+        else
+        {
+          cur[2] += step[2];
+          tmax[2] = __fadd_rn(tmax[2], tdelta[2]);
+        }
+        active = prev < length;
+      }
+    }
+    int end;
+    const bool head = run_heads(key, lane, end);
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1)
+    {
+      const float t = __shfl_down(dd, s2);
+      if (lane + s2 < end)
+        dd += t;
+    }
+    if (head && key != 0xffffffffu)
+    {
+      unsafeAtomicAdd(&ray[key], dd);
       any = true;
-    }
-    prev = dist;
-    const int ci = i == 0 ? cur[0] : (i == 1 ? cur[1] : cur[2]);
-    const int li = i == 0 ? last[0] : (i == 1 ? last[1] : last[2]);
-    if (ci == li)
-      break;
-    if (i == 0)
-    {
-      cur[0] += step[0];
-      tmax[0] = __fadd_rn(tmax[0], tdelta[0]);
-    }
-    else if (i == 1)
-    {
-      cur[1] += step[1];
-      tmax[1] = __fadd_rn(tmax[1], tdelta[1]);
-    }
-    else
-    {
-      cur[2] += step[2];
-      tmax[2] = __fadd_rn(tmax[2], tdelta[2]);
     }
   }
   if (any)
@@ -245,71 +270,51 @@ __global__ __launch_bounds__(256) void k_gscan_c(const uint32_t* __restrict__ in
 
 // ------------------------------------------------------------------ sepclusters
 
-// K16a: transposed occupancy image.  Bit t = z + y*sz + x*sz*sy of `tbits` is set iff map(x,y,z) > thr,
-// read from the x-fastest occupancy image (small, cache resident) so the float map is not re-streamed.
-__global__ __launch_bounds__(256) void k_transpose_bits(const MapGeom mg, const unsigned long long* __restrict__ mapbits, unsigned long long* __restrict__ tbits)
+// K16: voxelsAsVoxelPC (voxel_map.cpp:187-212) enumerates the thresholded voxels x-outer / y / z-inner.  One lane
+// owns one (x,y) column; lanes of a wave are consecutive in x, so the occupancy word of a (y,z) row is fetched
+// once per wave and every lane tests its own bit.  Pass 1 counts the set bits per column into x-major order,
+// a scan turns the counts into each column's first position, pass 2 writes the points (x,y,z as floats, map value)
+// and the "sure" flags the counted grid's positional count consumes.
+__global__ __launch_bounds__(256) void k_col_count(const MapGeom mg, const unsigned long long* __restrict__ mapbits, uint32_t* __restrict__ colcount_t)
 {
-  const uint64_t n_words = (mg.n + 63) >> 6;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  const uint64_t szy = static_cast<uint64_t>(mg.sz) * mg.sy;
-  for (uint64_t w = wave; w < n_words; w += n_waves)
-  {
-    const uint64_t t = w * 64 + lane;
-    bool set = false;
-    if (t < mg.n)
-    {
-      const uint64_t x = t / szy;
-      const uint64_t rem = t - x * szy;
-      const uint64_t y = rem / mg.sz;
-      const uint64_t z = rem - y * mg.sz;
-      const uint64_t li = (z * mg.sy + y) * mg.sx + x;
-      set = (mapbits[li >> 6] >> (li & 63)) & 1ull;
-    }
-    const unsigned long long b = __ballot(set);
-    if (lane == 0)
-      tbits[w] = b;
-  }
-}
-
-// word popcounts of a plain bitmap -> u32 array (input of the generic scan)
-__global__ __launch_bounds__(256) void k_popc_words(const unsigned long long* __restrict__ bits, uint32_t n_words, uint32_t* __restrict__ out)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_words)
-    out[i] = __popcll(bits[i]);
-}
-
-// K16b: voxelsAsVoxelPC (voxel_map.cpp:187-212): emit (x,y,z as floats, map value) in transposed-bit order
-// plus the "sure" flag (value > sure threshold) that the counted grid's positional count consumes.
-__global__ __launch_bounds__(256) void k_emit_vpc(const MapGeom mg, const float* __restrict__ map, const unsigned long long* __restrict__ tbits,
-                                                  const uint32_t* __restrict__ tprefix, uint32_t n_words, float thr_sure, float* __restrict__ px,
-                                                  float* __restrict__ py, float* __restrict__ pz, float* __restrict__ pi, uint32_t* __restrict__ sure)
-{
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words)
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ncol = static_cast<uint32_t>(mg.sx) * mg.sy;
+  if (t >= ncol)
     return;
-  unsigned long long bits = tbits[w];
-  uint32_t rank = tprefix[w];
-  const uint64_t szy = static_cast<uint64_t>(mg.sz) * mg.sy;
-  while (bits)
-  {
-    const int b = __ffsll(static_cast<long long>(bits)) - 1;
-    bits &= bits - 1;
-    const uint64_t t = static_cast<uint64_t>(w) * 64 + b;
-    const uint64_t x = t / szy;
-    const uint64_t rem = t - x * szy;
-    const uint64_t y = rem / mg.sz;
-    const uint64_t z = rem - y * mg.sz;
-    const float m = map[(z * mg.sy + y) * mg.sx + x];
-    px[rank] = static_cast<float>(x);
-    py[rank] = static_cast<float>(y);
-    pz[rank] = static_cast<float>(z);
-    pi[rank] = m;
-    sure[rank] = m > thr_sure ? 1u : 0u;
-    rank++;
-  }
+  const uint32_t x = t % mg.sx, y = t / mg.sx;
+  const uint64_t plane = static_cast<uint64_t>(mg.sx) * mg.sy;
+  uint32_t c = 0;
+  uint64_t li = t;
+  for (int z = 0; z < mg.sz; z++, li += plane)
+    c += static_cast<uint32_t>((mapbits[li >> 6] >> (li & 63)) & 1ull);
+  colcount_t[x * mg.sy + y] = c;
+}
+
+__global__ __launch_bounds__(256) void k_col_emit(const MapGeom mg, const float* __restrict__ map, const unsigned long long* __restrict__ mapbits,
+                                                  const uint32_t* __restrict__ colbase_t, float thr_sure, float* __restrict__ px, float* __restrict__ py,
+                                                  float* __restrict__ pz, float* __restrict__ pi, uint32_t* __restrict__ sure)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ncol = static_cast<uint32_t>(mg.sx) * mg.sy;
+  if (t >= ncol)
+    return;
+  const uint32_t x = t % mg.sx, y = t / mg.sx;
+  const uint64_t plane = static_cast<uint64_t>(mg.sx) * mg.sy;
+  uint32_t pos = colbase_t[x * mg.sy + y];
+  if (colbase_t[x * mg.sy + y + 1] == pos)
+    return;  // empty column
+  uint64_t li = t;
+  for (int z = 0; z < mg.sz; z++, li += plane)
+    if ((mapbits[li >> 6] >> (li & 63)) & 1ull)
+    {
+      const float m = map[li];
+      px[pos] = static_cast<float>(x);
+      py[pos] = static_cast<float>(y);
+      pz[pos] = static_cast<float>(z);
+      pi[pos] = m;
+      sure[pos] = m > thr_sure ? 1u : 0u;
+      pos++;
+    }
 }
 
 // per-voxel point counts of the weighted emission -> u32 array
@@ -344,11 +349,26 @@ __global__ __launch_bounds__(256) void k_flag_over(const char* __restrict__ col,
 __global__ __launch_bounds__(256) void k_cluster_sure(const FrameHdr* hdr, const float4* __restrict__ pts, const uint32_t* __restrict__ labels, uint32_t* __restrict__ n_sure)
 {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= hdr->V)
-    return;
-  const uint32_t r = __float_as_uint(pts[v].w);
-  if (r)
-    atomicAdd(&n_sure[labels[v]], r);
+  const int lane = threadIdx.x & 63;
+  uint32_t key = 0xffffffffu, r = 0;
+  if (v < hdr->V)
+  {
+    r = __float_as_uint(pts[v].w);
+    if (r)
+      key = labels[v];
+  }
+  // consecutive voxels mostly share the cluster: one atomic per run of equal labels inside the wave
+  int end;
+  const bool head = run_heads(key, lane, end);
+#pragma unroll
+  for (int s2 = 1; s2 < 64; s2 <<= 1)
+  {
+    const uint32_t t = __shfl_down(r, s2);
+    if (lane + s2 < end)
+      r += t;
+  }
+  if (head && key != 0xffffffffu)
+    atomicAdd(&n_sure[key], r);
 }
 
 __global__ __launch_bounds__(256) void k_any_sure(const FrameHdr* hdr, const uint32_t* __restrict__ labels, const uint32_t* __restrict__ n_sure, uint32_t min_sure, uint32_t* out)

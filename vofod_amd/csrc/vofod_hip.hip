@@ -276,7 +276,9 @@ struct vofod_handle
   vt::Geom hg{};
   float *d_map = nullptr, *d_flags = nullptr, *d_ray = nullptr;
   unsigned long long* d_mapbits = nullptr;
-  unsigned long long* d_counter = nullptr;  // [0] nVoxelsOver, [1..] scratch
+  unsigned long long* d_counter = nullptr;  // scratch words
+  unsigned long long *d_bgcount = nullptr, *h_bgcount = nullptr;  // MB_SLOTS partial nVoxelsOver counters (64 B apart); host pinned copy
+  bool bgcount_fresh = false;
   unsigned long long* h_counter = nullptr;  // pinned
   bool mapbits_valid = false;
   float mapbits_thr = 0;
@@ -788,9 +790,10 @@ int ensure_mapbits(vofod_handle* h, float thr)
 {
   if (h->mapbits_valid && h->mapbits_thr == thr)
     return VOFOD_OK;
-  HIPCHK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
-  KLAUNCH(h, k_mapbits, dim3(256 * 8), dim3(256), h->d_map, h->mg.n, thr, h->d_mapbits, h->d_counter);
-  HIPCHK(hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_bgcount, 0, sizeof(unsigned long long) * 8 * MB_SLOTS, h->stream));
+  KLAUNCH(h, k_mapbits, dim3(1024), dim3(256), h->d_map, h->mg.n, thr, h->d_mapbits, h->d_bgcount);
+  HIPCHK(hipMemcpyAsync(h->h_bgcount, h->d_bgcount, sizeof(unsigned long long) * 8 * MB_SLOTS, hipMemcpyDeviceToHost, h->stream));
+  h->bgcount_fresh = true;
   h->mapbits_valid = true;
   h->mapbits_thr = thr;
   return VOFOD_OK;  // h_counter is valid after the next stream sync
@@ -1068,7 +1071,14 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   if (!no_update)
     h->mapbits_valid = false;
 
-  h->n_bg_voxels = h->h_counter[0];
+  if (h->bgcount_fresh)
+  {
+    uint64_t t = 0;
+    for (int i = 0; i < MB_SLOTS; i++)
+      t += h->h_bgcount[8 * i];
+    h->n_bg_voxels = t;
+    h->bgcount_fresh = false;
+  }
   if (h->n_bg_voxels > h->background_min_sufficient_pts)  // :716-721
     h->background_pts_sufficient = true;
   if (!no_update)
