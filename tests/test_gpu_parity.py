@@ -222,3 +222,47 @@ def test_old_raycast_rule(oracle, hip):
         d.process_scan(scans[1].scan, scans[1].tf)
         assert d.raycast_finish() == capi.OK
     np.testing.assert_allclose(dev.read_map(), ref.read_map(), rtol=1e-4, atol=1e-3)
+
+
+def test_aos_ouster_layout_and_device_input(oracle, hip):
+    """the 48-byte ouster_ros::Point AoS (x +0, y +4, z +8, intensity +16, range +36) through the strided-column view"""
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
+    scene = synth.make_scene(5, n_targets=2)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    s0, s1 = synth.scan_sequence(scene, "os1-16", 2, seed0=900)
+    n = s0.x.size
+    aos = np.zeros(n, dtype=np.dtype({"names": ["x", "y", "z", "intensity", "range"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u4"], "offsets": [0, 4, 8, 16, 36], "itemsize": 48}))
+    for k in ("x", "y", "z", "intensity", "range"):
+        aos[k] = getattr(s0, k)
+    base = aos.ctypes.data
+    from vofod_amd.detector import ScanData
+
+    scan_aos = ScanData(x=base, y=base + 4, z=base + 8, intensity=base + 16, range=base + 36, width=s0.scan.width, height=s0.scan.height, stride_bytes=48)
+    for d in (ref, dev):
+        d.process_scan(scan_aos, s0.tf)
+        assert d.raycast_begin(scan_aos, s0.tf) == capi.OK
+    dr, gr = ref.process_scan(s1.scan, s1.tf, debug=True)
+    dh, gh = dev.process_scan(s1.scan, s1.tf, debug=True)
+    assert_scan_debug_equal(gr, gh)
+    assert ref.raycast_finish() == dev.raycast_finish() == capi.OK
+    ma, mb = ref.read_map(), dev.read_map()
+    np.testing.assert_allclose(mb, ma, rtol=1e-4, atol=1e-3)
+    # device-resident columns (what bench.py hands over)
+    import ctypes as C
+
+    rt = C.CDLL("libamdhip64.so")  # the runtime the product already loaded (torch is not needed for device memory)
+    rt.hipMalloc.argtypes, rt.hipMemcpy.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    cols = np.ascontiguousarray(np.stack([s1.x, s1.y, s1.z]))
+    dptr = C.c_void_p()
+    assert rt.hipMalloc(C.byref(dptr), cols.nbytes) == 0
+    assert rt.hipMemcpy(dptr, cols.ctypes.data_as(C.c_void_p), cols.nbytes, 1) == 0  # hipMemcpyHostToDevice
+    col = s1.x.nbytes
+    scan_dev = ScanData(x=dptr.value, y=dptr.value + col, z=dptr.value + 2 * col, width=s1.scan.width, height=s1.scan.height, stride_bytes=4, memspace=capi.MEM_DEVICE)
+    sync_maps(ref, dev)
+    da, ga = ref.process_scan(s1.scan, s1.tf, flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+    db, gb = dev.process_scan(scan_dev, s1.tf, flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+    assert_scan_debug_equal(ga, gb)
+    assert_detections_equal(da, db)
+    rt.hipFree.argtypes = [C.c_void_p]
+    rt.hipFree(dptr)

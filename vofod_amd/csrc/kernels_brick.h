@@ -205,8 +205,12 @@ __global__ __launch_bounds__(256) void k_brick_union(const GridParams g, const B
       }
       if (conn)
       {
-        // union(b, nb) with the representative of b kept in a register
-        uint32_t ra = uf_find<2>(ba.bparent, rv), rb = uf_find<2>(ba.bparent, nb);
+        // union(b, nb) with the representative of b kept in a register.  Cheap exit first: once the forest has
+        // settled most neighbours hang directly under our representative (one load instead of two chases).
+        const uint32_t pn = *reinterpret_cast<volatile uint32_t*>(&ba.bparent[nb]);
+        if (pn == rv)
+          continue;
+        uint32_t ra = uf_find<2>(ba.bparent, rv), rb = (pn == nb) ? nb : uf_find<2>(ba.bparent, pn);
         while (ra != rb)
         {
           if (ra < rb)
