@@ -240,6 +240,13 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
                         vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out,
                         vofod_scan_debug* dbg);
 
+/* The same, pipelined: submit enqueues the kernel chain of a batch and returns a ticket (0 or 1; at most two batches
+ * in flight), collect waits for it, runs the classification tail and returns the detections.  Submitting batch k+1
+ * before collecting batch k hides the host-side tail behind the device work of the next batch.  Read-only map only
+ * (VOFOD_SCAN_NO_MAP_UPDATE semantics); collect in submit order for deterministic detection ids. */
+int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket);
+int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out);
+
 /* raycast_cloud :1397-1605 split where the reference thread blocks on m_detection_cv (:1530-1537):
  *   begin  = guards :1400-1423, start_detection_its :1425, clear + DDA accumulation :1430-1492
  *   finish = detection_its_diff :1539, max :1542, update sweep :1550-1601, flags clear :1602 */

@@ -62,6 +62,15 @@ struct vofod_handle
   std::vector<vofod_point_xyzr> sep_ds;
   std::vector<vo::Cluster> sep_clusters;
   std::vector<size_t> sep_n_sure;
+
+  // vofod_batch_submit / vofod_batch_collect: the oracle simply computes at submit time
+  struct Ticket
+  {
+    bool pending = false;
+    std::vector<vofod_detection> dets;
+    std::vector<uint32_t> per_frame;
+    int status = VOFOD_OK;
+  } tickets[2];
 };
 
 namespace
@@ -869,6 +878,57 @@ int ORACLE_API(process_batch)(vofod_handle* h, const vofod_scan* scans, const fl
   }
   *n_out = total;
   return ret;
+}
+
+int ORACLE_API(batch_submit)(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket)
+{
+  if (!h || !scans || !tfs || !ticket)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  const int t = !h->tickets[0].pending ? 0 : (!h->tickets[1].pending ? 1 : -1);
+  if (t < 0)
+    return VOFOD_ERR_CAPACITY;
+  auto& T = h->tickets[t];
+  T.dets.clear();
+  T.per_frame.assign(n, 0);
+  T.status = VOFOD_OK;
+  // ids are handed out at collect time (collect order), as in the product: compute with a scratch counter and renumber then
+  const uint32_t id0 = h->last_detection_id;
+  for (size_t f = 0; f < n; f++)
+  {
+    vofod_detection buf[256];
+    size_t nf = 0;
+    const int r = process_scan_locked(h, &scans[f], tfs + 12 * f, VOFOD_SCAN_NO_MAP_UPDATE, static_cast<uint32_t>(f), buf, 256, &nf, nullptr);
+    if (r != VOFOD_OK)
+      T.status = r;
+    T.per_frame[f] = static_cast<uint32_t>(nf);
+    T.dets.insert(T.dets.end(), buf, buf + std::min<size_t>(nf, 256));
+  }
+  h->last_detection_id = id0;
+  T.pending = true;
+  *ticket = t;
+  return VOFOD_OK;
+}
+
+int ORACLE_API(batch_collect)(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out)
+{
+  if (!h || !n_out || ticket < 0 || ticket > 1)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  auto& T = h->tickets[ticket];
+  if (!T.pending)
+    return VOFOD_ERR_NOT_PENDING;
+  T.pending = false;
+  for (auto& d : T.dets)
+    d.id = h->last_detection_id++;
+  *n_out = T.dets.size();
+  if (n_out_per_frame)
+    std::copy(T.per_frame.begin(), T.per_frame.end(), n_out_per_frame);
+  if (T.dets.size() > cap)
+    return VOFOD_ERR_CAPACITY;
+  if (out)
+    std::copy(T.dets.begin(), T.dets.end(), out);
+  return T.status;
 }
 
 int ORACLE_API(raycast_begin)(vofod_handle* h, const vofod_scan* scan, const float tf[12])

@@ -266,3 +266,37 @@ def test_aos_ouster_layout_and_device_input(oracle, hip):
     assert_detections_equal(da, db)
     rt.hipFree.argtypes = [C.c_void_p]
     rt.hipFree(dptr)
+
+
+def test_pipelined_batches_equal_synchronous(oracle, hip):
+    """vofod_batch_submit / vofod_batch_collect: two batches in flight give the detections of the synchronous calls"""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=4)
+    scene = synth.make_scene(21, n_targets=3)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+        for s in synth.scan_sequence(scene, "os1-128", 5, seed0=300):
+            d.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+    sync_maps(ref, dev)
+    batches = [synth.scan_sequence(scene, "os1-128", 4, seed0=310 + 10 * b) for b in range(3)]
+    want = []
+    for b in batches:
+        want.append(ref.process_batch([s.scan for s in b], np.stack([s.tf for s in b])))
+    scan_lists = [[s.scan for s in b] for b in batches]
+    tf_lists = [np.stack([s.tf for s in b]) for b in batches]
+    got = []
+    t_prev = dev.batch_submit(scan_lists[0], tf_lists[0])
+    for k in range(1, 3):
+        t_next = dev.batch_submit(scan_lists[k], tf_lists[k])  # batch k is enqueued before batch k-1 is collected
+        got.append(dev.batch_collect(t_prev))
+        t_prev = t_next
+    got.append(dev.batch_collect(t_prev))
+    assert sum(len(w[0]) for w in want) > 0
+    id0 = want[0][0]["id"][0] - got[0][0]["id"][0] if len(want[0][0]) else 0
+    for (wd, wp), (gd, gp) in zip(want, got):
+        np.testing.assert_array_equal(gp, wp)
+        gd = gd.copy()
+        gd["id"] += id0
+        assert_detections_equal(wd, gd)
+    with pytest.raises(Exception):
+        dev.batch_collect(0)

@@ -469,6 +469,7 @@ void vofod_destroy(vofod_handle* h)
   if (h->stream)
     (void)hipStreamSynchronize(h->stream);
   h->ws.release();
+  h->ws2.release();
   h->aux.release();
   h->sepws.release();
   void* ptrs[] = {h->d_map, h->d_flags, h->d_ray, h->d_mapbits, h->d_counter, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_rows, h->d_crows, h->d_boxstage, h->d_idxstage,
@@ -497,6 +498,8 @@ void vofod_destroy(vofod_handle* h)
     (void)hipHostFree(h->sep.h_small);
   if (h->stream)
     (void)hipStreamDestroy(h->stream);
+  if (h->stream_tail)
+    (void)hipStreamDestroy(h->stream_tail);
   delete h;
 }
 
@@ -529,6 +532,7 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   } while (0)
   CREATE_CHK(hipSetDevice(h->device));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream_tail, hipStreamNonBlocking));
   for (int a = 0; a < 3; a++)
   {
     h->exclude_center[a] = sp->exclude_offset[a];
@@ -723,7 +727,7 @@ int vofod_process_scan(vofod_handle* h, const vofod_scan* scan, const float tf[1
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
   *n_out = 0;
-  return process_frames(h, scan, tf, 1, flags, out, cap, nullptr, n_out, dbg);
+  return process_frames(h, h->ws, FRAMES_SYNC, scan, tf, 1, flags, out, cap, nullptr, n_out, dbg);
 }
 
 int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out,
@@ -740,7 +744,7 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
   {
     const uint32_t m = static_cast<uint32_t>(std::min<size_t>(h->ws.F, n - base));
     size_t got = 0;
-    const int r = process_frames(h, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
+    const int r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
                                  n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
     for (size_t i = total; i < std::min(total + got, cap); i++)
       out[i].frame += static_cast<uint32_t>(base);
@@ -750,6 +754,50 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
   }
   *n_out = total;
   return ret;
+}
+
+int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket)
+{
+  if (!h || !scans || !tfs || !ticket)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  if (n > h->ws.F)
+  {
+    h->err = "batch larger than max_batch_frames";
+    return VOFOD_ERR_CAPACITY;
+  }
+  if (h->ws2.F == 0)
+  {
+    if (hipError_t e = h->ws2.ensure(h->ws.F, h->ws.pt_cap, h->ws.vox_cap, h->ws.words_cap, h->ws.bricks_cap); e != hipSuccess)
+    {
+      h->err = std::string("second workspace: ") + hipGetErrorString(e);
+      return VOFOD_ERR_DEVICE;
+    }
+  }
+  Workspace* w = !h->ws.pending ? &h->ws : (!h->ws2.pending ? &h->ws2 : nullptr);
+  if (!w)
+  {
+    h->err = "two batches already in flight: collect one first";
+    return VOFOD_ERR_CAPACITY;
+  }
+  const int r = process_frames(h, *w, FRAMES_LAUNCH, scans, tfs, static_cast<uint32_t>(n), VOFOD_SCAN_NO_MAP_UPDATE, nullptr, 0, nullptr, nullptr, nullptr);
+  if (r == VOFOD_OK)
+    *ticket = (w == &h->ws) ? 0 : 1;
+  return r;
+}
+
+int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out)
+{
+  if (!h || !n_out || ticket < 0 || ticket > 1)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  Workspace& w = ticket == 0 ? h->ws : h->ws2;
+  if (!w.pending)
+    return VOFOD_ERR_NOT_PENDING;
+  *n_out = 0;
+  return process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);
 }
 
 int vofod_raycast_begin(vofod_handle* h, const vofod_scan* scan, const float tf[12])

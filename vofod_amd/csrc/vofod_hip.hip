@@ -175,6 +175,12 @@ struct Workspace
   PackedFrame* d_packed = nullptr;
   PackedFrame* h_packed = nullptr;  // pinned
   std::vector<FrameArgs> h_args;
+  // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
+  bool pending = false;
+  uint32_t job_n = 0;
+  GridParams job_g{};
+  std::vector<float> job_tfs;
+  hipEvent_t ev_done = nullptr;
 
   void release()
   {
@@ -184,6 +190,8 @@ struct Workspace
         (void)hipFree(p);
     if (h_packed)
       (void)hipHostFree(h_packed);
+    if (ev_done)
+      (void)hipEventDestroy(ev_done);
     *this = Workspace();
   }
 
@@ -235,6 +243,8 @@ struct Workspace
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
     h_args.assign(F, FrameArgs{});
+    if ((e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess)
+      return e;
     return hipSuccess;
   }
 };
@@ -268,6 +278,8 @@ struct vofod_handle
   Prof prof;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_tail = nullptr;  // tail (k_explore) of collected async batches
+  Workspace ws2;                      // second frame workspace of the submit/collect pipeline
 
   float exclude_center[3], oparea_center[3];
   uint64_t background_min_sufficient_pts = 0;
@@ -964,15 +976,23 @@ int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, const vt::
 }
 
 // The body of processMsg (vofod_nodelet.cpp:926-965) for n frames.
-int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, uint32_t n, int flags, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame,
-                   size_t* n_out, vofod_scan_debug* dbg)
+enum FramesPhase { FRAMES_SYNC = 0, FRAMES_LAUNCH = 1, FRAMES_COLLECT = 2 };
+
+int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofod_scan* scans, const float* tfs, uint32_t n, int flags, vofod_detection* out, size_t cap,
+                   uint32_t* n_out_per_frame, size_t* n_out, vofod_scan_debug* dbg)
 {
   const vofod_static_params& sp = h->sp;
   const vofod_dyn_params& dp = h->dp;
-  Workspace& ws = h->ws;
+  if (phase == FRAMES_COLLECT)
+  {
+    n = ws.job_n;
+    tfs = ws.job_tfs.data();
+    flags = VOFOD_SCAN_NO_MAP_UPDATE;
+  }
   if (n == 0)
   {
-    *n_out = 0;
+    if (n_out)
+      *n_out = 0;
     return VOFOD_OK;
   }
   if (n > ws.F)
@@ -981,14 +1001,15 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
     return VOFOD_ERR_CAPACITY;
   }
   const size_t npts = static_cast<size_t>(sp.sensor_hrays) * sp.sensor_vrays;
-  for (uint32_t f = 0; f < n; f++)
-  {
-    const vofod_scan& s = scans[f];
-    if (!s.x || !s.y || !s.z)
-      return VOFOD_ERR_INVALID_ARG;
-    if (static_cast<size_t>(s.width) * s.height != npts)  // :895-899
-      return VOFOD_ERR_SIZE_MISMATCH;
-  }
+  if (phase != FRAMES_COLLECT)
+    for (uint32_t f = 0; f < n; f++)
+    {
+      const vofod_scan& s = scans[f];
+      if (!s.x || !s.y || !s.z)
+        return VOFOD_ERR_INVALID_ARG;
+      if (static_cast<size_t>(s.width) * s.height != npts)  // :895-899
+        return VOFOD_ERR_SIZE_MISMATCH;
+    }
   const bool no_update = flags & VOFOD_SCAN_NO_MAP_UPDATE;
   int ret = VOFOD_OK;
   auto t0 = clk::now();
@@ -999,6 +1020,11 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
     for (auto& e : ev)
       HIPCHK(hipEventCreate(&e));
 
+  GridParams g;
+  int r = VOFOD_OK;
+  const float thr_new = static_cast<float>(dp.voxel_map__thresholds__new_obstacles);
+  if (phase != FRAMES_COLLECT)
+  {
   // ---- stage inputs, K1-K6 (filterAndTransform :621-684)
   for (uint32_t f = 0; f < n; f++)
   {
@@ -1007,7 +1033,6 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
     if (r != VOFOD_OK)
       return r;
   }
-  GridParams g;
   const float leaf[3] = {sp.voxel_size, sp.voxel_size, sp.voxel_size};
   const int zero[3] = {0, 0, 0};
   float align_center[3];
@@ -1015,7 +1040,7 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   fill_grid_params(h, g, leaf, true, align_center, ws);
   if (dbg)
     HIPCHK(hipEventRecord(ev[0], h->stream));
-  int r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false);
+  r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false);
   if (r != VOFOD_OK)
     return r;
   if (dbg)
@@ -1029,7 +1054,6 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
     HIPCHK(hipEventRecord(ev[2], h->stream));
 
   // ---- K8/K9 findCloseFarClusters :703-750
-  const float thr_new = static_cast<float>(dp.voxel_map__thresholds__new_obstacles);
   r = ensure_mapbits(h, thr_new);
   if (r != VOFOD_OK)
     return r;
@@ -1066,7 +1090,25 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
   if (dbg)
     HIPCHK(hipEventRecord(ev[4], h->stream));
   tr_launch = ms_since(t0);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (phase == FRAMES_LAUNCH)
+  {
+    HIPCHK(hipEventRecord(ws.ev_done, h->stream));
+    ws.pending = true;
+    ws.job_n = n;
+    ws.job_g = g;
+    ws.job_tfs.assign(tfs, tfs + 12 * static_cast<size_t>(n));
+    return VOFOD_OK;
+  }
+  }  // launch part
+  else
+    g = ws.job_g;
+  if (phase == FRAMES_COLLECT)
+  {
+    HIPCHK(hipEventSynchronize(ws.ev_done));
+    ws.pending = false;
+  }
+  else
+    HIPCHK(hipStreamSynchronize(h->stream));
   tr_sync1 = ms_since(t0);
   if (!no_update)
     h->mapbits_valid = false;
@@ -1263,9 +1305,21 @@ int process_frames(vofod_handle* h, const vofod_scan* scans, const float* tfs, u
     any_host |= T.host_fallback;
   if (!jobs.empty() && !any_host)
   {
-    r = ensure_explore(h, ws.F, jobs.size(), job_members.size() / 3);
+    r = ensure_explore(h, std::max(h->ws.F, ws.F), jobs.size(), job_members.size() / 3);
     if (r != VOFOD_OK)
       return r;
+    // a collected async batch runs its tail on a second stream so that it does not queue behind the next batch's chain
+    struct StreamSwap
+    {
+      vofod_handle* h;
+      hipStream_t saved;
+      StreamSwap(vofod_handle* h_, bool on) : h(h_), saved(h_->stream)
+      {
+        if (on)
+          h->stream = h->stream_tail;
+      }
+      ~StreamSwap() { h->stream = saved; }
+    } swap_guard(h, phase == FRAMES_COLLECT);
     ExploreBufs& eb = h->explore;
     HIPCHK(hipMemcpyAsync(eb.d_jobs, jobs.data(), sizeof(vc::ExploreJob) * jobs.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(eb.d_job_begin, job_begin.data(), sizeof(uint32_t) * (n + 1), hipMemcpyHostToDevice, h->stream));

@@ -78,6 +78,8 @@ class VoFOD:
                 assert a.size == cnt, f"{name}: expected {cnt} elements, got {a.size}"
                 self._keep.append(a)
                 setattr(self.sp, name, a.ctypes.data_as(C.c_void_p))
+        self._scan_arrays = {}
+        self._pending = {}
         self.h = C.c_void_p()
         st = lib.create(C.byref(self.sp), C.byref(self.dp), C.byref(self.h))
         if st != capi.OK:
@@ -192,6 +194,28 @@ class VoFOD:
         if debug:
             return out, per, [self._dbg_dict(dbgs[f], bufs[f]) for f in range(n)]
         return out, per
+
+    def batch_submit(self, scans: Sequence[ScanData], tfs: np.ndarray) -> int:
+        """Enqueue a batch (read-only map); returns the ticket for `batch_collect`.  At most two in flight."""
+        n = len(scans)
+        key = id(scans)
+        cached = self._scan_arrays.get(key)
+        if cached is None or cached[0] != n:
+            cached = (n, (capi.Scan * n)(*[s.as_c() for s in scans]), scans)  # keeps `scans` alive: the key is its id
+            self._scan_arrays[key] = cached
+        tfa = np.ascontiguousarray(tfs, dtype=np.float32).reshape(n, 12)
+        ticket = C.c_int(-1)
+        self._check(self.lib.batch_submit(self.h, cached[1], capi.ptr(tfa), n, C.byref(ticket)), "vofod_batch_submit")
+        self._pending[ticket.value] = n
+        return ticket.value
+
+    def batch_collect(self, ticket: int, det_cap: int = 4096):
+        n = self._pending.pop(ticket)
+        dets = np.zeros(det_cap, dtype=capi.DETECTION)
+        per = np.zeros(n, dtype=np.uint32)
+        n_out = C.c_size_t(0)
+        self._check(self.lib.batch_collect(self.h, ticket, capi.ptr(dets), det_cap, capi.ptr(per), C.byref(n_out)), "vofod_batch_collect")
+        return dets[: n_out.value].copy(), per
 
     def raycast_begin(self, scan: ScanData, tf: np.ndarray, allow: Sequence[int] = ()):
         tfa = np.ascontiguousarray(tf, dtype=np.float32).reshape(12)
