@@ -485,7 +485,7 @@ void vofod_destroy(vofod_handle* h)
     if (p)
       (void)hipFree(p);
   for (auto& c : h->ctab)
-    for (void* p : {static_cast<void*>(c.d_rows), static_cast<void*>(c.d_boffs), static_cast<void*>(c.d_sure), static_cast<void*>(c.d_amb)})
+    for (void* p : {static_cast<void*>(c.d_rows), static_cast<void*>(c.d_boffs), static_cast<void*>(c.d_sure), static_cast<void*>(c.d_amb), static_cast<void*>(c.d_pair)})
       if (p)
         (void)hipFree(p);
   if (h->h_counter)

@@ -18,12 +18,18 @@ namespace vk
 {
 
 // MODE 0: agent-scope relaxed loads (L2-served) and stores; 1: agent loads, no path compression;
-//      2: plain loads/stores (L1-cached; stale parents are ancestors, the hooking CAS stays coherent)
+//      2: volatile loads/stores; 3: plain loads/stores (L1-cached; stale parents are ancestors, the hooking CAS stays coherent)
 template <int MODE>
 __device__ __forceinline__ uint32_t uf_ld(const uint32_t* p)
 {
   if (MODE == 2)
     return *reinterpret_cast<const volatile uint32_t*>(p);
+  if (MODE == 3)
+  {
+    const uint32_t v = *p;  // plain, L1-cached: a stale parent is still an ancestor; the compiler barrier forbids reuse across iterations
+    asm volatile("" ::: "memory");
+    return v;
+  }
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int MODE>
@@ -33,6 +39,8 @@ __device__ __forceinline__ void uf_st(uint32_t* p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else if (MODE == 2)
     *reinterpret_cast<volatile uint32_t*>(p) = v;
+  else if (MODE == 3)
+    *p = v;
 }
 
 // representative with intermediate pointer jumping (parents only ever decrease)

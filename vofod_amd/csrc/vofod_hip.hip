@@ -161,6 +161,7 @@ struct Workspace
 {
   uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0, bricks_cap = 0;
   BrickArrays ba{};
+  unsigned long long* d_bconn = nullptr;  // per brick: connectivity mask over the forward stencil (transitive reduction)
   FrameArgs* d_args = nullptr;
   FrameHdr* d_hdrs = nullptr;
   unsigned long long* d_bitmaps = nullptr;
@@ -184,7 +185,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {ba.bricks, ba.bparent, ba.bmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -219,6 +220,7 @@ struct Workspace
     WS_ALLOC(ba.bricks, sizeof(unsigned long long) * F * std::max<size_t>(bricks_cap, 1));
     if ((e = hipMemset(ba.bricks, 0, sizeof(unsigned long long) * F * std::max<size_t>(bricks_cap, 1))) != hipSuccess)
       return e;
+    WS_ALLOC(d_bconn, sizeof(unsigned long long) * F * std::max<size_t>(bricks_cap, 1));
     WS_ALLOC(ba.bparent, sizeof(uint32_t) * F * std::max<size_t>(bricks_cap, 1));
     WS_ALLOC(ba.bmin, sizeof(uint32_t) * F * std::max<size_t>(bricks_cap, 1));
     WS_ALLOC(ba.blist, sizeof(uint32_t) * FV);
@@ -313,6 +315,7 @@ struct vofod_handle
     BrickParams bp{};
     BrickOff* d_boffs = nullptr;
     unsigned long long *d_sure = nullptr, *d_amb = nullptr;
+    int8_t* d_pair = nullptr;  // [64*64] stencil index of offset(o2) - offset(o1), -1 when outside the forward stencil
   } ctab[2];
   int ctab_next = 0;
   struct CloseTables
@@ -756,6 +759,23 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       HIPCHK(hipMemcpy(ct->d_amb, amb.data(), sizeof(unsigned long long) * amb.size(), hipMemcpyHostToDevice));
       ct->bp.n_off = static_cast<int>(offs.size());
       ct->bp.r2 = ct->cp.r2;
+      if (ct->d_pair)
+        (void)hipFree(ct->d_pair);
+      ct->d_pair = nullptr;
+      if (offs.size() <= 64)
+      {
+        std::vector<int8_t> pair(64 * 64, -1);
+        for (size_t o1 = 0; o1 < offs.size(); o1++)
+          for (size_t o2 = 0; o2 < offs.size(); o2++)
+          {
+            const int dx = offs[o2].dx - offs[o1].dx, dy = offs[o2].dy - offs[o1].dy, dz = offs[o2].dz - offs[o1].dz;
+            for (size_t o3 = 0; o3 < offs.size(); o3++)
+              if (offs[o3].dx == dx && offs[o3].dy == dy && offs[o3].dz == dz)
+                pair[o1 * 64 + o2] = static_cast<int8_t>(o3);
+          }
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_pair), pair.size()));
+        HIPCHK(hipMemcpy(ct->d_pair, pair.data(), pair.size(), hipMemcpyHostToDevice));
+      }
     }
     ct->tol = tol;
     ct->cmax = cmax;
@@ -774,13 +794,16 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     BrickParams bp = ct->bp;
     bp.bricks_cap = ws.bricks_cap;
     KLAUNCH(h, k_brick_set, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
-    static const int bmode = std::getenv("VOFOD_BRICK_MODE") ? std::atoi(std::getenv("VOFOD_BRICK_MODE")) : 1;  // 2 = masks + batched hooking: measured slower
-    if (bmode == 2 && bp.n_off <= 64)
+    static const int bmode = std::getenv("VOFOD_BRICK_MODE") ? std::atoi(std::getenv("VOFOD_BRICK_MODE")) : 3;  // 1 fused probe+union, 2 masks + batched hooking (slower), 3 masks + transitive reduction
+    if ((bmode == 2 || bmode == 3) && bp.n_off <= 64 && ct->d_pair)
     {
-      // ws.d_table is free until k_finalize: it holds the per-brick connectivity masks in between
+      // ws.d_table is free until k_finalize: it holds the per-brick connectivity masks (list order) in between
       unsigned long long* conn = reinterpret_cast<unsigned long long*>(ws.d_table);
-      KLAUNCH(h, k_brick_conn, fgrid(g, gv * CONN_LANES), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba, conn);
-      KLAUNCH(h, k_brick_link, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ws.d_hdrs, ws.ba, conn);
+      KLAUNCH(h, k_brick_conn, fgrid(g, gv * CONN_LANES), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba, conn, bmode == 3 ? ws.d_bconn : nullptr);
+      if (bmode == 3)
+        KLAUNCH(h, k_brick_link_tr, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_pair, ws.d_hdrs, ws.ba, conn, ws.d_bconn);
+      else
+        KLAUNCH(h, k_brick_link, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ws.d_hdrs, ws.ba, conn);
     }
     else
       KLAUNCH(h, k_brick_union<1>, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
