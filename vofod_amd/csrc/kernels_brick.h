@@ -30,47 +30,6 @@ struct BrickOff
   unsigned long long ua, ub;  // bits of this brick / of the neighbour brick that have any partner at this offset
 };
 
-struct BrickParams
-{
-  int32_t n_off;
-  float r2;
-  uint32_t bricks_cap;
-};
-
-struct BrickArrays
-{
-  unsigned long long* bricks;  // occupancy words, all-zero outside a call (cleaned after use)
-  uint32_t* bparent;
-  uint32_t* bmin;   // per brick root: smallest voxel rank of the component
-  uint32_t* blist;  // occupied bricks of the frame (unordered), hdr.n_bricks entries
-};
-
-__device__ __forceinline__ BrickArrays frame_bricks(const BrickArrays& base, uint32_t frame, uint32_t bricks_cap, uint32_t vox_cap)
-{
-  BrickArrays b;
-  b.bricks = base.bricks + static_cast<size_t>(frame) * bricks_cap;
-  b.bparent = base.bparent + static_cast<size_t>(frame) * bricks_cap;
-  b.bmin = base.bmin + static_cast<size_t>(frame) * bricks_cap;
-  b.blist = base.blist + static_cast<size_t>(frame) * vox_cap;
-  return b;
-}
-
-__device__ __forceinline__ void key_to_ijk(const FrameHdr& h, uint32_t key, int& i, int& j, int& k)
-{
-  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
-  k = key / dxy;
-  const int rem = key - k * dxy;
-  j = rem / dx;
-  i = rem - j * dx;
-}
-
-__device__ __forceinline__ uint32_t brick_of(const FrameHdr& h, int i, int j, int k, int& bit)
-{
-  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
-  bit = (i & 3) | ((j & 3) << 2) | ((k & 3) << 4);
-  return static_cast<uint32_t>(((k >> 2) * nby + (j >> 2)) * nbx + (i >> 2));
-}
-
 // mark every voxel in its brick word; the first voxel of a brick registers it
 __global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const BrickParams bp, FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all)
 {
@@ -80,36 +39,17 @@ __global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const Bri
   (void)GX;
   FrameHdr& h = hdrs[FRAME];
   const uint32_t v = BX * blockDim.x + threadIdx.x;
-  const bool active = v < h.V;
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
   uint32_t b = 0;
   bool first = false;
-  if (active)
+  if (v < h.V)
   {
-    int i, j, k, bit;
+    int i, j, k;
     key_to_ijk(h, va.key[v], i, j, k);
-    b = brick_of(h, i, j, k, bit);
-    first = atomicOr(&ba.bricks[b], 1ull << bit) == 0ull;
+    first = brick_mark(h, ba, i, j, k, v, b);
   }
-  // list append: one counter atomic per wave instead of one per new brick (same-address atomics serialise)
-  const unsigned long long m = __ballot(first);
-  if (m)
-  {
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll(static_cast<long long>(m)) - 1;
-    uint32_t base = 0;
-    if (lane == leader)
-      base = atomicAdd(&h.n_bricks, static_cast<uint32_t>(__popcll(m)));
-    base = __shfl(base, leader);
-    if (first)
-    {
-      const uint32_t slot = base + __popcll(m & ((1ull << lane) - 1ull));
-      ba.blist[slot] = b;
-      ba.bparent[b] = b;
-      ba.bmin[b] = 0xffffffffu;
-    }
-  }
+  brick_append(h, ba, first, b);
 }
 
 template <int BRICK_LANES>
@@ -525,35 +465,53 @@ __global__ __launch_bounds__(256) void k_brick_link_tr(const GridParams g, const
   }
 }
 
-// per voxel: representative brick of its component (stored in labels[]), smallest voxel rank per component
-__global__ __launch_bounds__(256) void k_brick_min(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all,
-                                                   uint32_t* labels_all)
+// per occupied brick: point it straight at its representative and fold its smallest voxel rank into the component's.
+// A brick's smallest rank belongs to its lowest set bit (bit order inside a brick is the key order), and that voxel's
+// rank comes from the occupancy bitmap's prefix array: no per-voxel atomics.  Consecutive list entries mostly share
+// the component, so the atomicMin on the representative is issued once per run of equal representatives in the wave.
+__global__ __launch_bounds__(256) void k_brick_root(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, BrickArrays ba_all,
+                                                    const unsigned long long* __restrict__ bitmaps, const uint32_t* __restrict__ wprefix_all)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
   (void)GX;
   const FrameHdr& h = hdrs[FRAME];
-  const uint32_t v = BX * blockDim.x + threadIdx.x;
-  const bool active = v < h.V;
-  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const uint32_t t = BX * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
-  uint32_t R = 0xffffffffu;
-  if (active)
+  uint32_t R = 0xffffffffu, vmin = 0xffffffffu;
+  if (t < h.n_bricks)
   {
-    int i, j, k, bit;
-    key_to_ijk(h, va.key[v], i, j, k);
-    R = brick_of(h, i, j, k, bit);
+    const uint32_t b = ba.blist[t];
+    R = b;
     uint32_t p;
-    while ((p = ba.bparent[R]) != R)
+    while ((p = uf_ld<UFM>(&ba.bparent[R])) != R)
       R = p;
-    labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v] = R;
+    if (R != b)
+      ba.bparent[b] = R;  // still an ancestor for every concurrent chase through b
+    const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
+    const int bz = b / (nbx * nby);
+    const int brem = b - bz * nbx * nby;
+    const int by = brem / nbx;
+    const int bx = brem - by * nbx;
+    const int bit = __ffsll(static_cast<long long>(ba.bricks[b])) - 1;
+    const uint32_t key = static_cast<uint32_t>(((4 * bz + (bit >> 4)) * h.div_b[1] + (4 * by + ((bit >> 2) & 3))) * h.div_b[0] + 4 * bx + (bit & 3));
+    const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+    const uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+    vmin = rank_of(bm, wprefix, key);
   }
-  // consecutive voxels mostly share the component: one atomicMin per run of equal roots inside the wave
-  const uint32_t prevR = __shfl_up(R, 1);
-  const bool head = active && ((threadIdx.x & 63) == 0 || prevR != R);
-  if (head)
-    atomicMin(&ba.bmin[R], v);  // lanes are in ascending v, so the head of a run holds its minimum
+  int end;
+  const bool head = run_heads(R, lane, end);
+#pragma unroll
+  for (int s2 = 1; s2 < 64; s2 <<= 1)
+  {
+    const uint32_t o = __shfl_down(vmin, s2);
+    if (lane + s2 < end)
+      vmin = min(vmin, o);
+  }
+  if (head && R != 0xffffffffu)
+    atomicMin(&ba.bcmin[R], vmin);
 }
 
 __global__ __launch_bounds__(256) void k_brick_clear(const GridParams g, const BrickParams bp, const FrameHdr* hdrs, BrickArrays ba_all)
@@ -567,7 +525,10 @@ __global__ __launch_bounds__(256) void k_brick_clear(const GridParams g, const B
   if (t >= h.n_bricks)
     return;
   const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
-  ba.bricks[ba.blist[t]] = 0ull;
+  const uint32_t b = ba.blist[t];
+  ba.bricks[b] = 0ull;
+  ba.bmin[b] = 0xffffffffu;
+  ba.bcmin[b] = 0xffffffffu;
 }
 
 }  // namespace vk

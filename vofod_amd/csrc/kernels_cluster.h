@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
 // so that the one giant ground cluster does not serialise thousands of global atomics on seven addresses.
 constexpr int FL_SLOTS = 64;
 template <int SRC>
-__global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all, const uint32_t* bmin_all,
+__global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all, const BrickArrays ba_all,
                                                  uint32_t bricks_cap)
 {
   uint32_t FRAME, BX, GX;
@@ -217,6 +217,12 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
   int ijk[3] = {0, 0, 0};
   if (active)
   {
+    const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+    const uint32_t key = va.key[v];
+    ijk[2] = key / dxy;
+    const int rem = key - ijk[2] * dxy;
+    ijk[1] = rem / dx;
+    ijk[0] = rem - ijk[1] * dx;
     if (SRC == 0)
     {
       root = v;
@@ -225,14 +231,14 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
         root = p;
     }
     else
-      root = bmin_all[static_cast<size_t>(FRAME) * bricks_cap + labels[v]];
+    {
+      // brick path: k_brick_root left every brick pointing at its representative, whose bcmin is the component's label
+      const BrickArrays ba = frame_bricks(ba_all, FRAME, bricks_cap, g.vox_cap);
+      int bit;
+      const uint32_t b = brick_of(h, ijk[0], ijk[1], ijk[2], bit);
+      root = ba.bcmin[ba.bparent[b]];
+    }
     labels[v] = root;
-    const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
-    const uint32_t key = va.key[v];
-    ijk[2] = key / dxy;
-    const int rem = key - ijk[2] * dxy;
-    ijk[1] = rem / dx;
-    ijk[0] = rem - ijk[1] * dx;
   }
   // wave level: reduce the wave's leading cluster with shuffles
   const unsigned long long m_active = __ballot(active);

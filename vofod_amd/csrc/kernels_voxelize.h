@@ -419,21 +419,95 @@ __device__ __forceinline__ VoxelArrays frame_voxels(const VoxelArrays& base, uin
   return v;
 }
 
+// ---- brick bookkeeping shared by the emission kernel and kernels_brick.h -------------------------------------
+struct BrickParams
+{
+  int32_t n_off;
+  float r2;
+  uint32_t bricks_cap;
+};
+
+struct BrickArrays
+{
+  unsigned long long* bricks;  // occupancy words, all-zero outside a call (cleaned after use)
+  uint32_t* bparent;
+  uint32_t* bmin;   // per brick: smallest voxel rank inside the brick (0xffffffff outside a call)
+  uint32_t* bcmin;  // per brick root: smallest voxel rank of the whole component (0xffffffff outside a call)
+  uint32_t* blist;  // occupied bricks of the frame (unordered), hdr.n_bricks entries
+};
+
+__device__ __forceinline__ BrickArrays frame_bricks(const BrickArrays& base, uint32_t frame, uint32_t bricks_cap, uint32_t vox_cap)
+{
+  BrickArrays b;
+  b.bricks = base.bricks + static_cast<size_t>(frame) * bricks_cap;
+  b.bparent = base.bparent + static_cast<size_t>(frame) * bricks_cap;
+  b.bmin = base.bmin + static_cast<size_t>(frame) * bricks_cap;
+  b.bcmin = base.bcmin + static_cast<size_t>(frame) * bricks_cap;
+  b.blist = base.blist + static_cast<size_t>(frame) * vox_cap;
+  return b;
+}
+
+__device__ __forceinline__ void key_to_ijk(const FrameHdr& h, uint32_t key, int& i, int& j, int& k)
+{
+  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+  k = key / dxy;
+  const int rem = key - k * dxy;
+  j = rem / dx;
+  i = rem - j * dx;
+}
+
+__device__ __forceinline__ uint32_t brick_of(const FrameHdr& h, int i, int j, int k, int& bit)
+{
+  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
+  bit = (i & 3) | ((j & 3) << 2) | ((k & 3) << 4);
+  return static_cast<uint32_t>(((k >> 2) * nby + (j >> 2)) * nbx + (i >> 2));
+}
+
+
+// register voxel `rank` (lattice cell i,j,k) in its 4x4x4 brick; returns true for the brick's first voxel
+__device__ __forceinline__ bool brick_mark(const FrameHdr& h, const BrickArrays& ba, int i, int j, int k, uint32_t rank, uint32_t& b)
+{
+  int bit;
+  b = brick_of(h, i, j, k, bit);
+  (void)rank;
+  return atomicOr(&ba.bricks[b], 1ull << bit) == 0ull;
+}
+
+// append the bricks whose first voxel sits in this wave to the frame's brick list: one counter atomic per wave
+__device__ __forceinline__ void brick_append(FrameHdr& h, const BrickArrays& ba, bool first, uint32_t b)
+{
+  const unsigned long long m = __ballot(first);
+  if (!m)
+    return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll(static_cast<long long>(m)) - 1;
+  uint32_t base = 0;
+  if (lane == leader)
+    base = atomicAdd(&h.n_bricks, static_cast<uint32_t>(__popcll(m)));
+  base = __shfl(base, leader);
+  if (first)
+  {
+    ba.blist[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    ba.bparent[b] = b;
+  }
+}
+
 // K6: phase c of the scan fused with the emission of the weighted cloud in key order
 // (voxel_grid_weighted.cpp:155-188): centre = (ijk + 0.5)*leaf + offset, weight filled by k_count.
 // Emission is load-balanced: the block's words and per-thread rank offsets are staged in LDS and every
 // thread then produces output slots t, t+256, ... (locating the owning word by binary search), so the
 // voxel records leave the CU as coalesced 16-byte-per-lane stores regardless of how the set bits cluster.
-__global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
-                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all)
+__global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
+                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all, const BrickParams bp, BrickArrays ba_all, int brick_on)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
   (void)GX;
-  const FrameHdr& h = hdrs[FRAME];
+  FrameHdr& h = hdrs[FRAME];
   if (BX * SCAN_WPB >= h.n_words || h.V == 0)
     return;
+  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
   const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
@@ -469,50 +543,60 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, const FrameHdr
   }
   __syncthreads();
   const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
-  for (uint32_t t = threadIdx.x; t < total; t += 256)
+  const uint32_t total_round = (total + 63u) & ~63u;  // whole waves stay in the loop (brick_append shuffles)
+  for (uint32_t t = threadIdx.x; t < total_round; t += 256)
   {
-    // owner thread j: s_start[j] <= t < s_start[j+1]
-    int lo = 0, hi = 256;
-    while (hi - lo > 1)
+    bool first = false;
+    uint32_t brick = 0;
+    if (t < total)
     {
-      const int mid = (lo + hi) >> 1;
-      if (s_start[mid] <= t)
-        lo = mid;
-      else
-        hi = mid;
+      // owner thread j: s_start[j] <= t < s_start[j+1]
+      int lo = 0, hi = 256;
+      while (hi - lo > 1)
+      {
+        const int mid = (lo + hi) >> 1;
+        if (s_start[mid] <= t)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      uint32_t u = t - s_start[lo];
+      int wi = lo * SCAN_WPT;
+      unsigned long long w = s_words[wi];
+      uint32_t pc = __popcll(w);
+      while (u >= pc)
+      {
+        u -= pc;
+        w = s_words[++wi];
+        pc = __popcll(w);
+      }
+      for (uint32_t q = 0; q < u; q++)
+        w &= w - 1;
+      const int b = __ffsll(static_cast<long long>(w)) - 1;
+      const uint32_t key = (wbase + wi) * 64u + b;
+      const uint32_t rank = base + t;
+      const int k2 = key / dxy;
+      const int rem = key - k2 * dxy;
+      const int k1 = rem / dx;
+      const int k0 = rem - k1 * dx;
+      float4 p;
+      p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
+      p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
+      p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+      p.w = __uint_as_float(0u);
+      va.pts[rank] = p;
+      va.key[rank] = key;
+      va.parent[rank] = rank;
+      va.csize[rank] = 0;
+      va.cclose[rank] = 0;
+      int* cb = &va.cbox[6 * rank];
+      cb[0] = cb[1] = cb[2] = 0x7fffffff;
+      cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+      if (brick_on)
+        first = brick_mark(h, ba, k0, k1, k2, rank, brick);
     }
-    uint32_t u = t - s_start[lo];
-    int wi = lo * SCAN_WPT;
-    unsigned long long w = s_words[wi];
-    uint32_t pc = __popcll(w);
-    while (u >= pc)
-    {
-      u -= pc;
-      w = s_words[++wi];
-      pc = __popcll(w);
-    }
-    for (uint32_t q = 0; q < u; q++)
-      w &= w - 1;
-    const int b = __ffsll(static_cast<long long>(w)) - 1;
-    const uint32_t key = (wbase + wi) * 64u + b;
-    const uint32_t rank = base + t;
-    const int k2 = key / dxy;
-    const int rem = key - k2 * dxy;
-    const int k1 = rem / dx;
-    const int k0 = rem - k1 * dx;
-    float4 p;
-    p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
-    p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
-    p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
-    p.w = __uint_as_float(0u);
-    va.pts[rank] = p;
-    va.key[rank] = key;
-    va.parent[rank] = rank;
-    va.csize[rank] = 0;
-    va.cclose[rank] = 0;
-    int* cb = &va.cbox[6 * rank];
-    cb[0] = cb[1] = cb[2] = 0x7fffffff;
-    cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+    if (brick_on)
+      brick_append(h, ba, first, brick);
   }
 }
 
