@@ -432,44 +432,82 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
   const bool active = v < h.V;
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const int lane = threadIdx.x & 63;
-  uint32_t root = 0;
+  uint32_t root = 0, hit_root = 0xffffffffu;
   int ox = 0, oy = 0, oz = 0;
   bool undecided = false;
   if (active)
-  {
     root = labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v];
-    if (!__hip_atomic_load(&va.cclose[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    {
-      const float4 p = va.pts[v];
-      // coordToIdx voxel_map.cpp:592-599
-      ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
-      oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
-      oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
-      if (cp.n_rows > 0 && close_row_hit(mg, mapbits, rows[0], ox, oy, oz))  // rows[0] is (dy,dz) = (0,0): nearest first
-        __hip_atomic_store(&va.cclose[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        undecided = true;
-    }
+  // the cluster's "already close" flag is read once per run of equal roots and handed to the run's lanes
+  uint32_t flag = 0;
+  {
+    const uint32_t key = active ? root : 0xffffffffu;
+    const uint32_t prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long H = __ballot(head);
+    if (head && active)
+      flag = __hip_atomic_load(&va.cclose[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long upto = H & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int head_lane = 63 - __clzll(static_cast<long long>(upto));
+    flag = __shfl(flag, head_lane);
   }
+  if (active && !flag)
+  {
+    const float4 p = va.pts[v];
+    // coordToIdx voxel_map.cpp:592-599
+    ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
+    oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
+    oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
+    if (cp.n_rows > 0 && close_row_hit(mg, mapbits, rows[0], ox, oy, oz))  // rows[0] is (dy,dz) = (0,0): nearest first
+      hit_root = root;
+    else
+      undecided = true;
+  }
+  {
+    // consecutive voxels mostly share the cluster: one flag store per run of equal roots, not one per lane
+    int end;
+    if (run_heads(hit_root, lane, end) && hit_root != 0xffffffffu)
+      __hip_atomic_store(&va.cclose[hit_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // Phase B: four undecided voxels at a time, 16 lanes each sweeping the stencil rows
   unsigned long long todo = __ballot(undecided);
-  uint32_t known_close = 0xffffffffu;  // a root this wave has just proven close
+  const int grp = lane >> 4, sub = lane & 15;
   while (todo)
   {
-    const int src = __ffsll(static_cast<long long>(todo)) - 1;
-    todo &= todo - 1;
-    const uint32_t r_root = __shfl(root, src);
-    if (r_root == known_close)
-      continue;
-    const int sx_ = __shfl(ox, src), sy_ = __shfl(oy, src), sz_ = __shfl(oz, src);
-    bool hit = false;
-    for (int r = 1 + lane; r < cp.n_rows && !hit; r += 64)
-      hit = close_row_hit(mg, mapbits, rows[r], sx_, sy_, sz_);
-    if (__ballot(hit))
+    // pick up to four source lanes
+    int src = -1;
+    unsigned long long rest = todo;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
     {
-      known_close = r_root;
-      if (lane == 0)
-        __hip_atomic_store(&va.cclose[r_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int s = rest ? __ffsll(static_cast<long long>(rest)) - 1 : -1;
+      if (rest)
+        rest &= rest - 1;
+      if (q == grp)
+        src = s;
     }
+    todo = rest;
+    const int srcl = src < 0 ? 0 : src;
+    const uint32_t r_root = __shfl(root, srcl);
+    const int sx_ = __shfl(ox, srcl), sy_ = __shfl(oy, srcl), sz_ = __shfl(oz, srcl);
+    // rows are ordered nearest first; a group stops as soon as any of its lanes has found an occupied cell
+    const unsigned long long gmask = 0xffffull << (grp * 16);
+    bool done = src < 0, found = false;
+    for (int r0 = 1; r0 < cp.n_rows; r0 += 16)
+    {
+      bool hit = false;
+      const int r = r0 + sub;
+      if (!done && r < cp.n_rows)
+        hit = close_row_hit(mg, mapbits, rows[r], sx_, sy_, sz_);
+      if (__ballot(hit) & gmask)
+      {
+        done = true;
+        found = true;
+      }
+      if (!__ballot(!done))
+        break;
+    }
+    if (found && sub == 0)
+      __hip_atomic_store(&va.cclose[r_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
