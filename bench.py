@@ -240,8 +240,12 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_flatten<0>": 8.0 * V * F,
         "k_flatten<1>": 8.0 * V * F,
         "k_brick_set": 4.0 * V * F,
-        "k_brick_union<1>": 16.0 * V * F,  # the voxels' share of "read centres/keys 16*V" (SURVEY 8d): the bricks hold them as bits
-        "k_brick_min": 8.0 * V * F,
+        # clustering stage of SURVEY 8d = read centres/keys 16*V + write labels 4*V + member list 4*V, split over its kernels:
+        "k_brick_union<1>": 20.0 * V * F,  # fused probe + link
+        "k_brick_conn": 16.0 * V * F,      # neighbourhood pass over the voxel positions (held as brick bits)
+        "k_brick_link_tr": 4.0 * V * F,    # component links = the labels' worth
+        "k_brick_link": 4.0 * V * F,
+        "k_brick_root": 4.0 * V * F,
         "k_closefar": 4.0 * V * F,
         "k_finalize": 12.0 * V * F,
         "k_mapbits": 4.0 * M + M / 8.0,
