@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--map-warm-scans", type=int, default=24)
     ap.add_argument("--cpu-baseline-scans", type=int, default=8, help="scans timed through the CPU oracle (0 disables)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
     return ap.parse_args()
 
 
@@ -79,10 +81,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collective's tensors live
 
     import vofod_amd
     from vofod_amd import capi, synth
@@ -113,8 +121,8 @@ def main():
     from vofod_amd import dist as vdist
 
     # all-gather payload: D_MAX 128-byte detection records + the count per frame, RCCL over xGMI
-    rec_local = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64, device=dev)
-    rec_all = torch.zeros((world, F, vdist.FRAME_F64), dtype=torch.float64, device=dev)
+    rec_local = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
+    rec_all = torch.zeros((world, F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
     rec_host = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64).pin_memory()
 
     def publish(dets, per):
@@ -151,7 +159,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
