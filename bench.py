@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=32, help="independent scans per GPU per step")
     ap.add_argument("--voxel-size", type=float, default=0.25)
     ap.add_argument("--sensor", default="os1-128")
-    ap.add_argument("--map-warm-scans", type=int, default=24)
+    ap.add_argument("--map-warm-scans", type=int, default=96)
     ap.add_argument("--cpu-baseline-scans", type=int, default=8, help="scans timed through the CPU oracle (0 disables)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")

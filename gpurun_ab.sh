@@ -1,4 +1,2 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-VOFOD_CCL=voxel python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cluster or sequence or golden" 2>&1 | tail -2
-python bench.py --steps 20 --warmup 3 --cpu-baseline-scans 0 > gpurun_out/bench3.json 2> gpurun_out/bench3.err; python -c "
-import json;d=json.load(open('gpurun_out/bench3.json'));print(round(d['value']),round(d['ms_per_step'],3),round(d['single_stream']['ms_per_scan'],3)); print({k:round(v['avg_us'],1) for k,v in d['kernels'].items()})"
+for w in 48 96; do python bench.py --steps 5 --warmup 1 --map-warm-scans $w --cpu-baseline-scans 0 --no-profile-pass > gpurun_out/bench_w$w.json 2> gpurun_out/bench_w$w.err; python -c "
+import json;d=json.load(open('gpurun_out/bench_w$w.json'));print('warm $w',round(d['value']),d['config']['detections_per_step'])"; done

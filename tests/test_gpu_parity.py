@@ -300,3 +300,68 @@ def test_pipelined_batches_equal_synchronous(oracle, hip):
         assert_detections_equal(wd, gd)
     with pytest.raises(Exception):
         dev.batch_collect(0)
+
+
+def test_dynamic_params_invalidate_cached_tables(oracle, hip):
+    """set_dynamic_params between scans: the cached cluster stencil / brick tables, hasCloseTo rows and the occupancy
+    image (threshold) must follow (m_drmgr_ptr->config may change between any two callbacks)"""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.25)
+    scene = synth.make_scene(13, n_targets=2)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    scans = synth.scan_sequence(scene, "os1-128", 4, seed0=40)
+    settings = [
+        dict(ground_points_max_distance=1.5),                       # brick family (tol/leaf = 6)
+        dict(ground_points_max_distance=0.8),                       # voxel family (tol/leaf = 3.2), other hasCloseTo rows
+        dict(voxel_map__thresholds__new_obstacles=-500.0),          # other occupancy image
+        dict(ground_points_max_distance=1.5, classification__min_points=1, voxel_map__scores__unknown=-700.0),
+    ]
+    for s, kv in zip(scans, settings):
+        for d in (ref, dev):
+            d.set_dynamic_params(**kv)
+        dr, gr = ref.process_scan(s.scan, s.tf, debug=True)
+        dh, gh = dev.process_scan(s.scan, s.tf, debug=True)
+        assert_scan_debug_equal(gr, gh)
+        assert_detections_equal(dr, dh)
+        np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+
+
+def test_concurrent_callers_are_serialised(hip):
+    """two threads hammer one handle (the nodelet's pointcloud / sepclusters threads): calls are serialised on the
+    handle's mutex and the result equals some sequential order (here: the map ends identical to a sequential replay
+    because the two roles touch it commutatively only through process_scan's order)"""
+    import threading
+
+    from helpers import make_pair as mk
+
+    _, dev = mk(hip, hip, "os1-16", 0.5)
+    _, seq = mk(hip, hip, "os1-16", 0.5)
+    scene = synth.make_scene(3)
+    scans = synth.scan_sequence(scene, "os1-16", 6, seed0=11)
+    for d in (dev, seq):
+        synth.seed_ground(d)
+    errs = []
+
+    def scan_role():
+        try:
+            for s in scans:
+                dev.process_scan(s.scan, s.tf)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    def status_role():
+        try:
+            for _ in range(200):
+                dev.status()
+                dev.read_map(capi.MAP_FLAGS)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=scan_role), threading.Thread(target=status_role)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for s in scans:
+        seq.process_scan(s.scan, s.tf)
+    np.testing.assert_array_equal(dev.read_map(), seq.read_map())
+    assert dev.status().detection_its == 6
