@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--map-warm-scans", type=int, default=96)
     ap.add_argument("--cpu-baseline-scans", type=int, default=8, help="scans timed through the CPU oracle (0 disables)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (1..4); their kernel chains overlap on the device")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
     return ap.parse_args()
@@ -135,16 +136,18 @@ def main():
         """k batches through the submit/collect pipeline: batch i+1 is enqueued before batch i is collected, so the host
         tail of one batch overlaps the device chain of the next.  Every batch is submitted and collected inside the call."""
         n_det = 0
-        ticket = det.batch_submit(scans, tfs)
-        for _ in range(k - 1):
-            nxt = det.batch_submit(scans, tfs)
-            dets, per = det.batch_collect(ticket)
+        inflight = []
+        for _ in range(k):
+            inflight.append(det.batch_submit(scans, tfs))
+            if len(inflight) == args.inflight:
+                dets, per = det.batch_collect(inflight.pop(0))
+                publish(dets, per)
+                n_det += len(dets)
+        while inflight:
+            dets, per = det.batch_collect(inflight.pop(0))
             publish(dets, per)
             n_det += len(dets)
-            ticket = nxt
-        dets, per = det.batch_collect(ticket)
-        publish(dets, per)
-        return n_det + len(dets)
+        return n_det
 
     def sync():
         if world > 1:
@@ -190,7 +193,7 @@ def main():
                 "map_voxels": det.n_voxels,
                 "map_warm_scans": args.map_warm_scans,
                 "detections_per_step": n_det / args.steps,
-                "pipeline": "vofod_batch_submit/collect, two batches in flight",
+                "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight on separate streams",
             },
         }
         # single-stream (stateful, sequential) latency of the same scan shape

@@ -240,8 +240,8 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
                         vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out,
                         vofod_scan_debug* dbg);
 
-/* The same, pipelined: submit enqueues the kernel chain of a batch and returns a ticket (0 or 1; at most two batches
- * in flight), collect waits for it, runs the classification tail and returns the detections.  Submitting batch k+1
+/* The same, pipelined: submit enqueues the kernel chain of a batch on its own stream and returns a ticket (0..3; at most four
+ * batches in flight, their chains overlap on the device), collect waits for it, runs the classification tail and returns the detections.  Submitting batch k+1
  * before collecting batch k hides the host-side tail behind the device work of the next batch.  Read-only map only
  * (VOFOD_SCAN_NO_MAP_UPDATE semantics); collect in submit order for deterministic detection ids. */
 int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket);

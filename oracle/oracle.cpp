@@ -70,7 +70,7 @@ struct vofod_handle
     std::vector<vofod_detection> dets;
     std::vector<uint32_t> per_frame;
     int status = VOFOD_OK;
-  } tickets[2];
+  } tickets[4];
 };
 
 namespace
@@ -885,7 +885,10 @@ int ORACLE_API(batch_submit)(vofod_handle* h, const vofod_scan* scans, const flo
   if (!h || !scans || !tfs || !ticket)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
-  const int t = !h->tickets[0].pending ? 0 : (!h->tickets[1].pending ? 1 : -1);
+  int t = -1;
+  for (int i = 0; i < 4 && t < 0; i++)
+    if (!h->tickets[i].pending)
+      t = i;
   if (t < 0)
     return VOFOD_ERR_CAPACITY;
   auto& T = h->tickets[t];
@@ -912,7 +915,7 @@ int ORACLE_API(batch_submit)(vofod_handle* h, const vofod_scan* scans, const flo
 
 int ORACLE_API(batch_collect)(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out)
 {
-  if (!h || !n_out || ticket < 0 || ticket > 1)
+  if (!h || !n_out || ticket < 0 || ticket > 3)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   auto& T = h->tickets[ticket];

@@ -469,7 +469,8 @@ void vofod_destroy(vofod_handle* h)
   if (h->stream)
     (void)hipStreamSynchronize(h->stream);
   h->ws.release();
-  h->ws2.release();
+  for (auto& w : h->wsx)
+    w.release();
   h->aux.release();
   h->sepws.release();
   void* ptrs[] = {h->d_map, h->d_flags, h->d_ray, h->d_mapbits, h->d_counter, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_rows, h->d_crows, h->d_boxstage, h->d_idxstage,
@@ -500,6 +501,9 @@ void vofod_destroy(vofod_handle* h)
     (void)hipStreamDestroy(h->stream);
   if (h->stream_tail)
     (void)hipStreamDestroy(h->stream_tail);
+  for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
+    if (h->chain_stream[t])
+      (void)hipStreamDestroy(h->chain_stream[t]);
   delete h;
 }
 
@@ -533,6 +537,9 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   CREATE_CHK(hipSetDevice(h->device));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream_tail, hipStreamNonBlocking));
+  h->chain_stream[0] = h->stream;
+  for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
+    CREATE_CHK(hipStreamCreateWithFlags(&h->chain_stream[t], hipStreamNonBlocking));
   for (int a = 0; a < 3; a++)
   {
     h->exclude_center[a] = sp->exclude_offset[a];
@@ -613,6 +620,7 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   h->sure_background_sufficient = false;  // :283-284
   h->background_pts_sufficient = false;
   h->last_detection_id = 0;  // :296
+  (void)hipDeviceSynchronize();  // null-stream memsets of the set-up are complete before any non-blocking stream runs
   *out = h;
   return VOFOD_OK;
 }
@@ -767,33 +775,37 @@ int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tf
     h->err = "batch larger than max_batch_frames";
     return VOFOD_ERR_CAPACITY;
   }
-  if (h->ws2.F == 0)
+  int t = -1;
+  for (int i = 0; i < vofod_handle::MAX_INFLIGHT && t < 0; i++)
+    if (!h->slot(i)->pending)
+      t = i;
+  if (t < 0)
   {
-    if (hipError_t e = h->ws2.ensure(h->ws.F, h->ws.pt_cap, h->ws.vox_cap, h->ws.words_cap, h->ws.bricks_cap); e != hipSuccess)
+    h->err = "four batches already in flight: collect one first";
+    return VOFOD_ERR_CAPACITY;
+  }
+  Workspace* w = h->slot(t);
+  if (w->F == 0)
+  {
+    if (hipError_t e = w->ensure(h->ws.F, h->ws.pt_cap, h->ws.vox_cap, h->ws.words_cap, h->ws.bricks_cap); e != hipSuccess)
     {
-      h->err = std::string("second workspace: ") + hipGetErrorString(e);
+      h->err = std::string("extra workspace: ") + hipGetErrorString(e);
       return VOFOD_ERR_DEVICE;
     }
   }
-  Workspace* w = !h->ws.pending ? &h->ws : (!h->ws2.pending ? &h->ws2 : nullptr);
-  if (!w)
-  {
-    h->err = "two batches already in flight: collect one first";
-    return VOFOD_ERR_CAPACITY;
-  }
   const int r = process_frames(h, *w, FRAMES_LAUNCH, scans, tfs, static_cast<uint32_t>(n), VOFOD_SCAN_NO_MAP_UPDATE, nullptr, 0, nullptr, nullptr, nullptr);
   if (r == VOFOD_OK)
-    *ticket = (w == &h->ws) ? 0 : 1;
+    *ticket = t;
   return r;
 }
 
 int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out)
 {
-  if (!h || !n_out || ticket < 0 || ticket > 1)
+  if (!h || !n_out || ticket < 0 || ticket >= vofod_handle::MAX_INFLIGHT)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
-  Workspace& w = ticket == 0 ? h->ws : h->ws2;
+  Workspace& w = *h->slot(ticket);
   if (!w.pending)
     return VOFOD_ERR_NOT_PENDING;
   *n_out = 0;

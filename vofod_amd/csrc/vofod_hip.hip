@@ -253,7 +253,8 @@ struct Workspace
     h_args.assign(F, FrameArgs{});
     if ((e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess)
       return e;
-    return hipSuccess;
+    // the memsets above run on the null stream, the kernels on non-blocking streams: wait for the fills to land
+    return hipDeviceSynchronize();
   }
 };
 
@@ -287,7 +288,10 @@ struct vofod_handle
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream_tail = nullptr;  // tail (k_explore) of collected async batches
-  Workspace ws2;                      // second frame workspace of the submit/collect pipeline
+  static constexpr int MAX_INFLIGHT = 4;
+  hipStream_t chain_stream[MAX_INFLIGHT] = {nullptr, nullptr, nullptr, nullptr};  // [0] == stream; in-flight batches run their chains on separate streams and overlap on the device
+  Workspace wsx[MAX_INFLIGHT - 1];                                                  // workspaces of tickets 1..3 (ticket 0 uses ws)
+  Workspace* slot(int t) { return t == 0 ? &ws : &wsx[t - 1]; }
 
   float exclude_center[3], oparea_center[3];
   uint64_t background_min_sufficient_pts = 0;
@@ -901,6 +905,7 @@ int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_ovl_count), sizeof(uint32_t) * F));
     HIPCHK(hipMemset(eb.d_ovl_count, 0, sizeof(uint32_t) * F));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_job_begin), sizeof(uint32_t) * (F + 1)));
+    HIPCHK(hipDeviceSynchronize());  // null-stream memsets vs non-blocking streams
   }
   if (eb.jobs_cap < n_jobs)
   {
@@ -1079,8 +1084,35 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   GridParams g;
   int r = VOFOD_OK;
   const float thr_new = static_cast<float>(dp.voxel_map__thresholds__new_obstacles);
+  struct ChainStream
+  {
+    vofod_handle* h;
+    hipStream_t saved;
+    ChainStream(vofod_handle* h_, hipStream_t st) : h(h_), saved(h_->stream)
+    {
+      if (st)
+        h->stream = st;
+    }
+    ~ChainStream() { h->stream = saved; }
+  };
+  // VOFOD_TWO_CHAINS=0 keeps every in-flight batch on one stream (measured 19 % slower: the kernels are latency bound)
+  static const bool two_chains = !(std::getenv("VOFOD_TWO_CHAINS") && std::atoi(std::getenv("VOFOD_TWO_CHAINS")) == 0);
+  hipStream_t my_stream = nullptr;
+  if (two_chains && phase == FRAMES_LAUNCH)
+    for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
+      if (&ws == h->slot(t))
+        my_stream = h->chain_stream[t];
   if (phase != FRAMES_COLLECT)
   {
+  ChainStream chain_guard(h, my_stream);
+  if (two_chains && phase == FRAMES_LAUNCH && !h->mapbits_valid)
+  {
+    // the occupancy image is shared by both chains: make sure it is complete before a second stream reads it
+    r = ensure_mapbits(h, thr_new);
+    if (r != VOFOD_OK)
+      return r;
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   // ---- stage inputs, K1-K6 (filterAndTransform :621-684)
   for (uint32_t f = 0; f < n; f++)
   {
@@ -1372,7 +1404,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     any_host |= T.host_fallback;
   if (!jobs.empty() && !any_host)
   {
-    r = ensure_explore(h, std::max(h->ws.F, ws.F), jobs.size(), job_members.size() / 3);
+    r = ensure_explore(h, h->ws.F, jobs.size(), job_members.size() / 3);
     if (r != VOFOD_OK)
       return r;
     // a collected async batch runs its tail on a second stream so that it does not queue behind the next batch's chain
