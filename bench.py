@@ -215,7 +215,7 @@ def main():
         if not args.no_profile_pass:
             out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F)
         if args.cpu_baseline_scans > 0:
-            out["cpu_baseline"] = cpu_baseline(args, scene, host_scans)
+            out["cpu_baseline"] = cpu_baseline(args, det, host_scans)
     sync()
     if rank == 0:
         print(json.dumps(out))
@@ -298,15 +298,18 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
     return roofline, kernels
 
 
-def cpu_baseline(args, scene, host_scans):
+def cpu_baseline(args, gpu_det, host_scans):
     """The CPU oracle ("port": restatement of the reference algorithm, 1 thread as pointcloud_threads: 1) timed on
-    a bounded sample of the same workload."""
+    a bounded sample of the same workload, starting from the very map the GPU run used."""
     from vofod_amd import capi
 
     so = ROOT / "oracle" / "libvofod_oracle.so"
     olib = capi.Library(so, "vofod_oracle_")
     det = build_detector(olib, args.sensor, args.voxel_size, 1, 0)
-    warm_map(det, scene, args.sensor, min(args.map_warm_scans, 6), seed0=1000)
+    st = gpu_det.status()
+    if st.background_pts_sufficient and st.sure_background_sufficient:
+        det.load_apriori(np.zeros((0, 3), dtype=np.float32))  # sets both latches, touches no voxel
+    det.write_map(capi.MAP_VOXELS, gpu_det.read_map(capi.MAP_VOXELS))
     n = args.cpu_baseline_scans
     t0 = time.perf_counter()
     for i in range(n):
@@ -319,7 +322,7 @@ def cpu_baseline(args, scene, host_scans):
         "cores": 1,
         "kind": "port",
         "sample": f"{n} process_scan calls over the benchmark's {len(host_scans)} OS1-128 scans through the C++ CPU oracle (restatement of the reference "
-        f"algorithm, not the PCL build; read-only map as in the batched mode), map warmed by {min(args.map_warm_scans, 6)} scans, {dt:.1f} s of CPU work, host has {os.cpu_count()} cores",
+        f"algorithm, not the PCL build; read-only map as in the batched mode) on the GPU run's own warmed map, {dt:.1f} s of CPU work, host has {os.cpu_count()} cores",
     }
 
 
