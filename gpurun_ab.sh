@@ -1,4 +1,3 @@
-timeout -k 10 120 python bench.py --steps 32 --warmup 4 --inflight 3 --cpu-baseline-scans 0 --no-profile-pass > gpurun_out/bench_i3.json 2> gpurun_out/bench_i3.err && python -c "
-import json;d=json.load(open('gpurun_out/bench_i3.json'));print('inflight 3',round(d['value']),round(d['ms_per_step'],3), d['config']['detections_per_step'])" && timeout -k 10 120 python bench.py --steps 32 --warmup 4 --inflight 4 --cpu-baseline-scans 0 --no-profile-pass > gpurun_out/bench_i4.json 2> gpurun_out/bench_i4.err && python -c "
-import json;d=json.load(open('gpurun_out/bench_i4.json'));print('inflight 4',round(d['value']),round(d['ms_per_step'],3), d['config']['detections_per_step'])" && timeout -k 10 120 python bench.py --steps 32 --warmup 4 --inflight 2 --cpu-baseline-scans 0 --no-profile-pass > gpurun_out/bench_i2.json 2> gpurun_out/bench_i2.err && python -c "
-import json;d=json.load(open('gpurun_out/bench_i2.json'));print('inflight 2',round(d['value']),round(d['ms_per_step'],3))"; tail -2 gpurun_out/bench_i3.err
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+python bench.py --steps 30 --warmup 3 --cpu-baseline-scans 0 > gpurun_out/bench3.json 2> gpurun_out/bench3.err; python -c "
+import json;d=json.load(open('gpurun_out/bench3.json'));print(round(d['value']),round(d['ms_per_step'],3),round(d['single_stream']['ms_per_scan'],3)); print({k:round(v['avg_us'],1) for k,v in d['kernels'].items()})"

@@ -59,6 +59,7 @@ struct GridParams
   uint32_t vox_cap;            // voxel records available per frame
   uint32_t n_frames;           // frames covered by the launch
   uint32_t xcd_map;            // 1: blocks of frame f are dealt to XCD f % 8 (per-frame working set stays in one L2)
+  uint32_t sparse_prefix;      // 1: word-prefix entries of all-empty bitmap blocks are not written (brick clustering only)
 };
 
 // One (dj,dk) row of the Euclidean-clustering half stencil.

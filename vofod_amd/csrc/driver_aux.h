@@ -974,6 +974,7 @@ int vofod_cluster(vofod_handle* h, const vofod_point_xyzr* pts, const uint32_t* 
       cbox[6 * i + 3 + c] = static_cast<int32_t>(0x80000000u);
     }
   HIPCHK(hipMemcpyAsync(ws.d_hdrs, &hdr, sizeof(hdr), hipMemcpyHostToDevice, h->stream));
+  ws.bitmap_clean = false;
   HIPCHK(hipMemcpyAsync(ws.d_bitmaps, bm.data(), sizeof(unsigned long long) * (words + 2), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(ws.d_wprefix, prefix.data(), sizeof(uint32_t) * (words + 2), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(ws.va.pts, pts, sizeof(float4) * n, hipMemcpyHostToDevice, h->stream));

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
 //     appended to the candidate member list the host-side classification consumes.
 __global__ __launch_bounds__(256) void k_finalize(const GridParams g, const MapGeom mg, const UpdateParams up, FrameHdr* hdrs, VoxelArrays va_all,
                                                   const uint32_t* labels_all, float* __restrict__ vmap, float* __restrict__ vflags, ClusterRec* table_all,
-                                                  CandMember* cand_all)
+                                                  CandMember* cand_all, unsigned long long* __restrict__ bitmaps)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
@@ -533,6 +533,9 @@ __global__ __launch_bounds__(256) void k_finalize(const GridParams g, const MapG
   const uint32_t close = va.cclose[root];
   const uint32_t size = va.csize[root];
   const float4 p = va.pts[v];
+  // last consumer of the frame's occupancy bitmap: leave it all-zero for the next call (no 2.5 MB memset per frame)
+  if (bitmaps)
+    bitmaps[static_cast<size_t>(FRAME) * (g.words_cap + 2) + (va.key[v] >> 6)] = 0ull;
   if (!up.no_update)
   {
     const int ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const Gr
 }
 
 // ---- exclusive prefix sum of the bitmap's word popcounts (3 phases) ------------------------
-constexpr int SCAN_WPT = 4;                    // words per thread
+constexpr int SCAN_WPT = 1;                    // words per thread
 constexpr int SCAN_WPB = 256 * SCAN_WPT;       // words per block
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
@@ -516,6 +516,23 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
   __shared__ unsigned long long s_words[SCAN_WPB];
   __shared__ uint32_t s_start[256 + 1];
   __shared__ uint32_t lds4[4];
+  {
+    // most blocks of the lattice hold no voxel at all: their total is known from the scan, so they leave without touching
+    // the bitmap.  Their words' prefix entries are only needed by the voxel-level clustering kernel (a neighbour window
+    // may start in an empty word); the brick family looks up ranks of set bits only (GridParams::sparse_prefix).
+    const uint32_t* bs = blocksums + static_cast<size_t>(FRAME) * nblk_cap;
+    const uint32_t nblk = (h.n_words + SCAN_WPB - 1) / SCAN_WPB;
+    const uint32_t mine = bs[BX], next = (BX + 1 < nblk) ? bs[BX + 1] : h.V;
+    if (next == mine)
+    {
+      if (!g.sparse_prefix)
+#pragma unroll
+        for (int k = 0; k < SCAN_WPT; k++)
+          if (w0 + k < h.n_words)
+            wprefix[w0 + k] = mine;
+      return;
+    }
+  }
   unsigned long long words[SCAN_WPT];
   uint32_t c = 0;
 #pragma unroll

@@ -177,6 +177,7 @@ struct Workspace
   PackedFrame* h_packed = nullptr;  // pinned
   std::vector<FrameArgs> h_args;
   bool bricks_preset = false;  // k_emit already registered the voxels in their bricks (fused brick_set)
+  bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
   // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
   bool pending = false;
   uint32_t job_n = 0;
@@ -558,6 +559,7 @@ void fill_grid_params(vofod_handle* h, GridParams& g, const float leaf[3], bool 
   g.vox_cap = ws.vox_cap;
   g.n_frames = 1;
   g.xcd_map = 0;
+  g.sparse_prefix = 0;
 }
 
 int ensure_boxstage(vofod_handle* h, size_t n)
@@ -710,7 +712,9 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
-  HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+  if (!ws.bitmap_clean)
+    HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * ws.F * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+  ws.bitmap_clean = false;  // set again by whoever runs the clearing pass
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
@@ -727,7 +731,8 @@ int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, ui
   const BrickParams* bricks = nullptr;
   ws.bricks_preset = false;
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
-  HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * n * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+  HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * ws.F * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+  ws.bitmap_clean = false;
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
@@ -1134,6 +1139,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     r = cluster_tables(h, g, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), &ct);
     if (r != VOFOD_OK)
       return r;
+    g.sparse_prefix = want_bricks(ct, ws) ? 1u : 0u;
     BrickParams bp = ct->bp;
     // Fusing the brick registration into k_emit was measured slower (194 us vs 96 + 50 us for 32 frames: the returning
     // atomicOr sits inside the load-balanced emission loop), so it stays a kernel of its own unless VOFOD_FUSE_BRICKS=1.
@@ -1183,7 +1189,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   up.min_points = dp.classification__min_points;
   up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
   up.no_update = no_update;
-  KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand);
+  KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, ws.d_bitmaps);
+  ws.bitmap_clean = true;
   KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
   HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
   if (dbg)
