@@ -221,6 +221,12 @@ int vofod_get_status(vofod_handle* h, vofod_status_info* out);
  * already transformed/downsampled by the caller (rows N2 of SURVEY 8f). */
 int vofod_load_apriori(vofod_handle* h, const float* xyz, size_t n);
 
+/* The whole of initialize_apriori_map (:214-226, :306-345) from a point-cloud file (row N2 of SURVEY 8f): load_cloud
+ * -> rigid transform (apriori_map/tf/{x,y,z,yaw} + sim_correction) -> stock pcl::VoxelGrid centroid filter at the map's
+ * voxel size -> vofod_load_apriori.  Init-time host work in the reference and here. */
+int vofod_ingest_apriori(vofod_handle* h, const char* filename, const float tf_xyz[3], double yaw_deg, const float sim_correction[3],
+                         size_t* n_loaded, size_t* n_voxels);
+
 /* test/visualisation access to the three maps (x-fastest, idx = ix + iy*sx + iz*sx*sy: voxel_map.cpp:81) */
 int vofod_read_map(vofod_handle* h, int which, float* dst, size_t n);
 int vofod_write_map(vofod_handle* h, int which, const float* src, size_t n);

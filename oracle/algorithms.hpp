@@ -520,4 +520,70 @@ inline void sim_lut(const int w, const int h, const float vfov, float* direction
     }
 }
 
+
+// initialize_apriori_map (vofod_nodelet.cpp:214-226, 306-345): rigid transform of the loaded cloud, stock
+// pcl::VoxelGrid<PointXYZ> centroid filter at the map's voxel size, centroids returned as xyz triples.
+// [3P] restated from PCL 1.10 voxel_grid.hpp / Eigen 3.3.7:
+//   tf = Identity; tf.rotate(AngleAxisf(yaw, UnitZ)); tf.translate(t + sim_correction)  ->  p' = R*p + R*(t+c)
+//   VoxelGrid: min_b = floor(min_p*inv), ijk = floor(x*inv) - min_b, idx = ijk . (1, dx, dx*dy), sort by idx,
+//   centroid = float sum of the run / count (order inside a run: input order; std::sort leaves it unspecified).
+inline void apriori_points(const std::vector<float>& xyz_in, const float t[3], double yaw_deg, const float corr[3], float leaf, std::vector<float>& out)
+{
+  out.clear();
+  const size_t n = xyz_in.size() / 3;
+  if (n == 0)
+    return;
+  const float angle = static_cast<float>(yaw_deg / 180.0 * M_PI);
+  const float c = std::cos(angle), s = std::sin(angle);
+  // AngleAxisf::toRotationMatrix() for axis (0,0,1)
+  const float R[9] = {c, -s, 0.0f, s, c, 0.0f, 0.0f, 0.0f, ((1.0f - c) * 1.0f) * 1.0f + c};
+  const float v[3] = {t[0] + corr[0], t[1] + corr[1], t[2] + corr[2]};
+  float tr[3];
+  for (int r = 0; r < 3; r++)
+    tr[r] = (R[3 * r] * v[0] + R[3 * r + 1] * v[1]) + R[3 * r + 2] * v[2];  // translationExt() += linearExt() * v
+  std::vector<float> p(3 * n);
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (size_t i = 0; i < n; i++)
+    for (int r = 0; r < 3; r++)
+    {
+      const float p0 = R[3 * r] * xyz_in[3 * i], p1 = R[3 * r + 1] * xyz_in[3 * i + 1], p2 = R[3 * r + 2] * xyz_in[3 * i + 2];
+      const float q = p0 + (p1 + (p2 + tr[r]));  // Transformer::se3
+      p[3 * i + r] = q;
+      mn[r] = std::min(mn[r], q);
+      mx[r] = std::max(mx[r], q);
+    }
+  const float inv = 1.0f / leaf;
+  int min_b[3], div_b[3];
+  for (int r = 0; r < 3; r++)
+  {
+    min_b[r] = static_cast<int>(std::floor(mn[r] * inv));
+    div_b[r] = static_cast<int>(std::floor(mx[r] * inv)) - min_b[r] + 1;
+  }
+  if (static_cast<int64_t>(div_b[0]) * div_b[1] * div_b[2] > 0x7fffffffll)
+    return;  // "Leaf size is too small": PCL warns and copies the input; an apriori cloud that large is not supported here
+  std::vector<std::pair<uint32_t, uint32_t>> order(n);
+  for (size_t i = 0; i < n; i++)
+  {
+    const int i0 = static_cast<int>(std::floor(p[3 * i] * inv) - static_cast<float>(min_b[0]));
+    const int i1 = static_cast<int>(std::floor(p[3 * i + 1] * inv) - static_cast<float>(min_b[1]));
+    const int i2 = static_cast<int>(std::floor(p[3 * i + 2] * inv) - static_cast<float>(min_b[2]));
+    order[i] = {static_cast<uint32_t>(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]), static_cast<uint32_t>(i)};
+  }
+  std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  for (size_t a = 0; a < n;)
+  {
+    size_t b = a;
+    float sum[3] = {0, 0, 0};
+    while (b < n && order[b].first == order[a].first)
+    {
+      for (int r = 0; r < 3; r++)
+        sum[r] += p[3 * order[b].second + r];
+      b++;
+    }
+    for (int r = 0; r < 3; r++)
+      out.push_back(sum[r] / static_cast<float>(b - a));
+    a = b;
+  }
+}
+
 }  // namespace vo

@@ -1076,6 +1076,26 @@ int ORACLE_API(load_cloud)(const char* filename, float* xyz, size_t cap, size_t*
   return n > cap ? VOFOD_ERR_CAPACITY : VOFOD_OK;
 }
 
+int ORACLE_API(ingest_apriori)(vofod_handle* h, const char* filename, const float tf_xyz[3], double yaw_deg, const float sim_correction[3], size_t* n_loaded,
+                               size_t* n_voxels)
+{
+  if (!h || !filename || !tf_xyz || !sim_correction)
+    return VOFOD_ERR_INVALID_ARG;
+  size_t n = 0;
+  int r = ORACLE_API(load_cloud)(filename, nullptr, 0, &n);
+  if (r != VOFOD_OK && r != VOFOD_ERR_CAPACITY)
+    return r;
+  std::vector<float> xyz(3 * n), cent;
+  if (n && (r = ORACLE_API(load_cloud)(filename, xyz.data(), n, &n)) != VOFOD_OK)
+    return r;
+  vo::apriori_points(xyz, tf_xyz, yaw_deg, sim_correction, h->sp.voxel_size, cent);
+  if (n_loaded)
+    *n_loaded = n;
+  if (n_voxels)
+    *n_voxels = cent.size() / 3;
+  return ORACLE_API(load_apriori)(h, cent.data(), cent.size() / 3);
+}
+
 int ORACLE_API(sim_lut)(int32_t w, int32_t h, float vfov, float* directions)
 {
   if (w < 2 || h < 2 || !directions)

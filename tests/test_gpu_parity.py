@@ -167,6 +167,26 @@ def test_process_scan_with_apriori_map_detects(oracle, hip):
     assert n_det > 0  # the floating boxes are found, identically on both sides
 
 
+def test_ingest_apriori_from_file(oracle, hip, tmp_path):
+    """row N2: file -> transform -> centroid grid -> +inf voxels, same map and same counts on both sides."""
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
+    scene = synth.make_scene(33, n_targets=1)
+    rng = np.random.default_rng(5)
+    ap = synth.apriori_points(scene, 0.2)  # finer than the map: several points per voxel, real centroids
+    ap = (ap + rng.normal(0, 0.03, ap.shape)).astype(np.float32)
+    f = tmp_path / "static.pts"
+    with open(f, "w") as fh:
+        fh.write(f"{len(ap)}\n")
+        np.savetxt(fh, ap, fmt="%.6f")
+    out = [d.ingest_apriori(str(f), (0.4, -0.3, 0.1), 17.5, (0.0, 0.0, 0.05)) for d in (ref, dev)]
+    assert out[0] == out[1] and out[0][0] == len(ap) and 0 < out[0][1] < len(ap)
+    a, b = ref.read_map(), dev.read_map()
+    np.testing.assert_array_equal(a, b)
+    assert np.isinf(a).sum() > 100
+    with pytest.raises(Exception):
+        dev.ingest_apriori(str(tmp_path / "missing.pts"))
+
+
 def test_no_map_update_and_batch_parity(oracle, hip):
     ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=4)
     scene = synth.make_scene(31, n_targets=2)

@@ -296,6 +296,27 @@ def test_load_cloud_text_formats(oracle, tmp_path):
         load_cloud(oracle, str(tmp_path / "missing.xyz"))
 
 
+def test_ingest_apriori_transform_and_centroids(oracle, tmp_path):
+    # vofod_nodelet.cpp:214-226 + :306-345.  yaw 90 deg, t=(1,0,0), correction (0,0,0.5): p' = R*(p + (1,0,0.5)),
+    # R = rot_z(90deg): (x,y,z) -> (-y, x, z) up to cos(pi/2 as float) = -4.37e-8.
+    sp, dp = default_params(oracle)
+    sp.voxel_size = 0.5
+    sp.oparea_offset[:] = (0.0, 0.0, -1.0)  # map spans x,y in [-4,4], z in [-1,3]  (:208-212)
+    sp.oparea_size[:] = (8.0, 8.0, 4.0)
+    d = VoFOD(oracle, sp, dp)
+    f = tmp_path / "map.xyz"
+    # two points sharing a 0.5 m cell after the transform (centroid = their mean), one alone, one outside the map
+    f.write_text("0.1 0.1 0.1\n0.3 0.2 0.2\n2.1 -1.1 1.0\n50 0 0\n")
+    nl, nv = d.ingest_apriori(str(f), (1.0, 0.0, 0.0), 90.0, (0.0, 0.0, 0.5))
+    assert (nl, nv) == (4, 3)
+    m = d.read_map()
+    inf = np.argwhere(np.isinf(m))
+    # centroid 1: (-0.15, 1.2, 0.65) -> idx ((x+4)/0.5, (y+4)/0.5, (z+1)/0.5) = (7, 10, 3)
+    # centroid 2: (1.1, 3.1, 1.5) -> (10, 14, 5);  the third (0, 51, 0.5) is outside the map
+    assert sorted(map(tuple, inf.tolist())) == [(3, 10, 7), (5, 14, 10)]
+    assert np.all(m[~np.isinf(m)] == m[0, 0, 0])
+
+
 def test_sim_lut_formula(oracle):
     # vofod_nodelet.cpp:374-420: yaw = col*2pi/(w-1), pitch = row*vfov/(h-1) - vfov/2
     lut = sim_lut(oracle, 1024, 128, math.radians(45.0)).reshape(128, 1024, 3)

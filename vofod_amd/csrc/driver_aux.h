@@ -1001,6 +1001,25 @@ int vofod_cluster(vofod_handle* h, const vofod_point_xyzr* pts, const uint32_t* 
   return VOFOD_OK;
 }
 
+int vofod_ingest_apriori(vofod_handle* h, const char* filename, const float tf_xyz[3], double yaw_deg, const float sim_correction[3], size_t* n_loaded, size_t* n_voxels)
+{
+  if (!h || !filename || !tf_xyz || !sim_correction)
+    return VOFOD_ERR_INVALID_ARG;
+  size_t n = 0;
+  int r = vofod_load_cloud(filename, nullptr, 0, &n);
+  if (r != VOFOD_OK && r != VOFOD_ERR_CAPACITY)
+    return r;
+  std::vector<float> xyz(3 * n), cent;
+  if (n && (r = vofod_load_cloud(filename, xyz.data(), n, &n)) != VOFOD_OK)
+    return r;
+  vt::ingest_apriori_points(xyz, tf_xyz, yaw_deg, sim_correction, h->sp.voxel_size, cent);  // init-time host work, as in the reference
+  if (n_loaded)
+    *n_loaded = n;
+  if (n_voxels)
+    *n_voxels = cent.size() / 3;
+  return vofod_load_apriori(h, cent.data(), cent.size() / 3);
+}
+
 int vofod_profile_enable(vofod_handle* h, int on)
 {
   if (!h)

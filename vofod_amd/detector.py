@@ -126,6 +126,14 @@ class VoFOD:
         a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         self._check(self.lib.load_apriori(self.h, capi.ptr(a), a.shape[0]), "vofod_load_apriori")
 
+    def ingest_apriori(self, filename: str, tf_xyz=(0.0, 0.0, 0.0), yaw_deg: float = 0.0, sim_correction=(0.0, 0.0, 0.0)):
+        """initialize_apriori_map from a .pts/.xyz file (apriori_map/tf/* of sim.yaml); returns (points loaded, voxels set)"""
+        t = np.ascontiguousarray(tf_xyz, dtype=np.float32)
+        c = np.ascontiguousarray(sim_correction, dtype=np.float32)
+        nl, nv = C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.ingest_apriori(self.h, filename.encode(), capi.ptr(t), float(yaw_deg), capi.ptr(c), C.byref(nl), C.byref(nv)), "vofod_ingest_apriori")
+        return nl.value, nv.value
+
     def read_map(self, which: int = capi.MAP_VOXELS) -> np.ndarray:
         """Returns the map as [sz, sy, sx] (x fastest: voxel_map.cpp:81)."""
         out = np.empty(self.n_voxels, dtype=np.float32)
