@@ -206,6 +206,39 @@ def test_no_map_update_and_batch_parity(oracle, hip):
     assert dev.status().detection_its == 0
 
 
+def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, monkeypatch):
+    """0.25 m voxels, tolerance 1.5 m: bricks are cliques, batches of >= 4 frames cluster inside LDS (k_brick_ccl_lds);
+    a frame with more bricks than the kernel takes makes the host run the batch again on the global-memory kernels."""
+    scene = synth.make_scene(41, n_targets=3)
+    scans = synth.scan_sequence(scene, "os1-128", 6, seed0=700)
+    tfs = np.stack([s.tf for s in scans])
+    for limit in (None, "64"):
+        if limit:
+            monkeypatch.setenv("VOFOD_LDS_MAX_BRICKS", limit)
+        ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=8)
+        for d in (ref, dev):
+            synth.seed_ground(d)
+        da, pa, ga = ref.process_batch([s.scan for s in scans], tfs, debug=True)
+        db, pb, gb = dev.process_batch([s.scan for s in scans], tfs, debug=True)
+        np.testing.assert_array_equal(pb, pa)
+        assert_detections_equal(da, db)
+        for x, y in zip(ga, gb):
+            assert_scan_debug_equal(x, y)
+        assert max(len(np.unique(x["labels"])) for x in ga) > 5
+        # pipelined form (fresh handle for the fallback case: the switch to the global kernels is per handle)
+        if limit:
+            ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=8)
+            for d in (ref, dev):
+                synth.seed_ground(d)
+        t0 = dev.batch_submit([s.scan for s in scans[:4]], tfs[:4])
+        t1 = dev.batch_submit([s.scan for s in scans[2:]], tfs[2:])
+        g0, g1 = dev.batch_collect(t0), dev.batch_collect(t1)
+        w0 = ref.process_batch([s.scan for s in scans[:4]], tfs[:4])
+        w1 = ref.process_batch([s.scan for s in scans[2:]], tfs[2:])
+        np.testing.assert_array_equal(g0[1], w0[1])
+        np.testing.assert_array_equal(g1[1], w1[1])
+
+
 def test_error_paths(oracle, hip):
     ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
     scene = synth.make_scene(1)

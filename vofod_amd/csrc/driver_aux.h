@@ -486,7 +486,7 @@ void vofod_destroy(vofod_handle* h)
     if (p)
       (void)hipFree(p);
   for (auto& c : h->ctab)
-    for (void* p : {static_cast<void*>(c.d_rows), static_cast<void*>(c.d_boffs), static_cast<void*>(c.d_sure), static_cast<void*>(c.d_amb), static_cast<void*>(c.d_pair)})
+    for (void* p : {static_cast<void*>(c.d_rows), static_cast<void*>(c.d_boffs), static_cast<void*>(c.d_sure), static_cast<void*>(c.d_amb), static_cast<void*>(c.d_pair), static_cast<void*>(c.d_lbtab)})
       if (p)
         (void)hipFree(p);
   if (h->h_counter)
@@ -752,8 +752,11 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
   {
     const uint32_t m = static_cast<uint32_t>(std::min<size_t>(h->ws.F, n - base));
     size_t got = 0;
-    const int r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
-                                 n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
+    int r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
+                           n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
+    if (r == CCL_RETRY_STATUS)  // see k_brick_ccl_lds: once per handle at most
+      r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
+                         n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
     for (size_t i = total; i < std::min(total + got, cap); i++)
       out[i].frame += static_cast<uint32_t>(base);
     total += got;
@@ -809,7 +812,15 @@ int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_
   if (!w.pending)
     return VOFOD_ERR_NOT_PENDING;
   *n_out = 0;
-  return process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);
+  int r = process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);
+  if (r == CCL_RETRY_STATUS)
+  {
+    // see k_brick_ccl_lds: the batch is enqueued again (global-memory clustering) from the submitted descriptors
+    r = process_frames(h, w, FRAMES_LAUNCH, w.job_scans.data(), w.job_tfs.data(), w.job_n, VOFOD_SCAN_NO_MAP_UPDATE, nullptr, 0, nullptr, nullptr, nullptr);
+    if (r == VOFOD_OK)
+      r = process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);
+  }
+  return r;
 }
 
 int vofod_raycast_begin(vofod_handle* h, const vofod_scan* scan, const float tf[12])

@@ -30,6 +30,55 @@ struct BrickOff
   unsigned long long ua, ub;  // bits of this brick / of the neighbour brick that have any partner at this offset
 };
 
+// Is any voxel of brick (bx,by,bz) with occupancy A within the tolerance of any voxel of the brick at stencil offset o
+// with occupancy B?  sure[o][p] / amb[o][p]: see the header comment; ambiguous pairs are decided by FLANN's float
+// expression on the actual centres.
+__device__ __forceinline__ bool brick_pair_conn(const GridParams& g, const BrickParams& bp, const FrameHdr& h, const BrickOff& off, int o,
+                                                const unsigned long long* __restrict__ sure, const unsigned long long* __restrict__ amb, unsigned long long A,
+                                                unsigned long long B, int bx, int by, int bz)
+{
+  const int nx = bx + off.dx, ny = by + off.dy, nz = bz + off.dz;
+  bool conn = false;
+  const unsigned long long* s = sure + static_cast<size_t>(o) * 64;
+  unsigned long long a = A & off.ua;
+  while (a && !conn)
+  {
+    const int p = __ffsll(static_cast<long long>(a)) - 1;
+    a &= a - 1;
+    conn = (s[p] & B) != 0ull;
+  }
+  if (!conn && off.has_amb)
+  {
+    const unsigned long long* m = amb + static_cast<size_t>(o) * 64;
+    a = A & off.ua;
+    while (a && !conn)
+    {
+      const int p = __ffsll(static_cast<long long>(a)) - 1;
+      a &= a - 1;
+      unsigned long long cand = m[p] & B;
+      if (!cand)
+        continue;
+      const float px = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+      const float py = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+      const float pz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+      while (cand && !conn)
+      {
+        const int q = __ffsll(static_cast<long long>(cand)) - 1;
+        cand &= cand - 1;
+        const float qx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nx + (q & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+        const float qy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * ny + ((q >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+        const float qz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nz + (q >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+        const float ddx = __fsub_rn(px, qx), ddy = __fsub_rn(py, qy), ddz = __fsub_rn(pz, qz);
+        float d2 = __fmul_rn(ddx, ddx);
+        d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
+        d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
+        conn = d2 < bp.r2;
+      }
+    }
+  }
+  return conn;
+}
+
 // mark every voxel in its brick word; the first voxel of a brick registers it
 __global__ __launch_bounds__(256) void k_brick_set(const GridParams g, const BrickParams bp, FrameHdr* hdrs, VoxelArrays va_all, BrickArrays ba_all)
 {
@@ -215,44 +264,7 @@ __global__ __launch_bounds__(256) void k_brick_conn(const GridParams g, const Br
       const unsigned long long B = ba.bricks[static_cast<uint32_t>((nz * nby + ny) * nbx + nx)];
       if (!(B & off.ub))
         continue;
-      bool conn = false;
-      const unsigned long long* s = sure + static_cast<size_t>(o) * 64;
-      unsigned long long a = A & off.ua;
-      while (a && !conn)
-      {
-        const int p = __ffsll(static_cast<long long>(a)) - 1;
-        a &= a - 1;
-        conn = (s[p] & B) != 0ull;
-      }
-      if (!conn && off.has_amb)
-      {
-        const unsigned long long* m = amb + static_cast<size_t>(o) * 64;
-        a = A & off.ua;
-        while (a && !conn)
-        {
-          const int p = __ffsll(static_cast<long long>(a)) - 1;
-          a &= a - 1;
-          unsigned long long cand = m[p] & B;
-          if (!cand)
-            continue;
-          const float px = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
-          const float py = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
-          const float pz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
-          while (cand && !conn)
-          {
-            const int q = __ffsll(static_cast<long long>(cand)) - 1;
-            cand &= cand - 1;
-            const float qx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nx + (q & 3)), 0.5f), g.leaf[0]), h.offset[0]);
-            const float qy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * ny + ((q >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
-            const float qz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * nz + (q >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
-            const float ddx = __fsub_rn(px, qx), ddy = __fsub_rn(py, qy), ddz = __fsub_rn(pz, qz);
-            float d2 = __fmul_rn(ddx, ddx);
-            d2 = __fadd_rn(d2, __fmul_rn(ddy, ddy));
-            d2 = __fadd_rn(d2, __fmul_rn(ddz, ddz));
-            conn = d2 < bp.r2;
-          }
-        }
-      }
+      const bool conn = brick_pair_conn(g, bp, h, off, o, sure, amb, A, B, bx, by, bz);
       if (conn)
         mask |= 1ull << o;
     }

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
       while ((p = va.parent[root]) != root)
         root = p;
     }
+    else if (SRC == 2)
+      root = labels[v];  // written by k_brick_ccl_lds
     else
     {
       // brick path: k_brick_root left every brick pointing at its representative, whose bcmin is the component's label
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
       const uint32_t b = brick_of(h, ijk[0], ijk[1], ijk[2], bit);
       root = ba.bcmin[ba.bparent[b]];
     }
-    labels[v] = root;
+    if (SRC != 2)
+      labels[v] = root;
   }
   // wave level: reduce the wave's leading cluster with shuffles
   const unsigned long long m_active = __ballot(active);

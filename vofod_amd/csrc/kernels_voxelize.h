@@ -404,6 +404,7 @@ struct VoxelArrays
   uint32_t* csize;     // per root: cluster size
   int32_t* cbox;       // per root: imin[3], imax[3]
   uint32_t* cclose;    // per root: close flag
+  uint32_t* bb;        // (4x4x4 brick id << 6) | bit inside the brick: spares the LDS clustering kernel the key decode
 };
 
 __device__ __forceinline__ VoxelArrays frame_voxels(const VoxelArrays& base, uint32_t frame, uint32_t vox_cap)
@@ -416,6 +417,7 @@ __device__ __forceinline__ VoxelArrays frame_voxels(const VoxelArrays& base, uin
   v.csize = base.csize + o;
   v.cbox = base.cbox + o * 6;
   v.cclose = base.cclose + o;
+  v.bb = base.bb + o;
   return v;
 }
 
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
       va.parent[rank] = rank;
       va.csize[rank] = 0;
       va.cclose[rank] = 0;
+      va.bb[rank] = (static_cast<uint32_t>(((k2 >> 2) * ((h.div_b[1] + 3) >> 2) + (k1 >> 2)) * ((h.div_b[0] + 3) >> 2) + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
       int* cb = &va.cbox[6 * rank];
       cb[0] = cb[1] = cb[2] = 0x7fffffff;
       cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);

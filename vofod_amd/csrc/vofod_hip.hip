@@ -20,6 +20,7 @@
 #include "host_tail.h"
 #include "thread_pool.h"
 #include "kernels_brick.h"
+#include "kernels_brick_lds.h"
 #include "kernels_classify.h"
 #include "kernels_cluster.h"
 #include "kernels_raycast.h"
@@ -177,6 +178,7 @@ struct Workspace
   PackedFrame* h_packed = nullptr;  // pinned
   std::vector<FrameArgs> h_args;
   bool bricks_preset = false;  // k_emit already registered the voxels in their bricks (fused brick_set)
+  std::vector<vofod_scan> job_scans;  // the submitted batch (re-run when the LDS clustering kernel overflows)
   bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
   // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
   bool pending = false;
@@ -187,7 +189,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -242,6 +244,7 @@ struct Workspace
     WS_ALLOC(va.csize, sizeof(uint32_t) * FV);
     WS_ALLOC(va.cbox, sizeof(int32_t) * 6 * FV);
     WS_ALLOC(va.cclose, sizeof(uint32_t) * FV);
+    WS_ALLOC(va.bb, sizeof(uint32_t) * FV);
     WS_ALLOC(d_labels, sizeof(uint32_t) * FV);
     WS_ALLOC(d_table, sizeof(ClusterRec) * FV);
     WS_ALLOC(d_cand, sizeof(CandMember) * FV);
@@ -281,6 +284,7 @@ struct HostCluster
 
 struct vofod_handle
 {
+  bool lds_ccl_off = false;  // a frame overflowed the LDS clustering kernel once: stay on the global-memory kernels
   std::mutex mtx;
   vofod_static_params sp{};
   vofod_dyn_params dp{};
@@ -327,6 +331,8 @@ struct vofod_handle
     BrickOff* d_boffs = nullptr;
     unsigned long long *d_sure = nullptr, *d_amb = nullptr;
     int8_t* d_pair = nullptr;  // [64*64] stencil index of offset(o2) - offset(o1), -1 when outside the forward stencil
+    LbTables* d_lbtab = nullptr;  // row / octant tables of k_brick_ccl_lds
+    bool lds_ok = false;
   } ctab[2];
   int ctab_next = 0;
   struct CloseTables
@@ -498,6 +504,75 @@ bool build_brick_tables(const float leaf[3], float tol, float cmax, std::vector<
         sure.insert(sure.end(), ms, ms + 64);
         amb.insert(amb.end(), ma, ma + 64);
       }
+  return true;
+}
+
+// Tables of k_brick_ccl_lds derived from the brick stencil: the offsets grouped into (dy,dz) rows, and per offset two
+// 8x8 bit matrices over 2x2x2 octants: sure8 (every voxel pair of the two octants is certainly within the tolerance)
+// and maybe8 (some pair is, certainly or on the boundary).
+bool build_lds_tables(const EdgeClassifier& classify, const std::vector<BrickOff>& offs, const std::vector<unsigned long long>& sure, const std::vector<unsigned long long>& amb,
+                      LbTables& t)
+{
+  std::memset(&t, 0, sizeof(t));
+  // ball tables: every relative voxel offset the predicate can accept must lie within LB_RV per axis
+  for (int c = LB_RV + 1; c <= 4 * 4 + 3; c++)
+    if (classify(c, 0, 0) != 0 || classify(0, c, 0) != 0 || classify(0, 0, c) != 0)
+      return false;
+  for (int dz = -LB_RV; dz <= LB_RV; dz++)
+    for (int dy = -LB_RV; dy <= LB_RV; dy++)
+      for (int dx = -LB_RV; dx <= LB_RV; dx++)
+      {
+        const int c = classify(dx, dy, dz);
+        if (c == 1)
+          t.ball_sure[dz + LB_RV][dy + LB_RV] |= static_cast<uint16_t>(1u << (dx + LB_RV));
+        else if (c == 2)
+          t.ball_amb[dz + LB_RV][dy + LB_RV] |= static_cast<uint16_t>(1u << (dx + LB_RV));
+      }
+  if (offs.empty() || offs.size() > LB_MAX_OFF)
+    return false;
+  int R = 0;
+  for (const auto& o : offs)
+    R = std::max(R, std::abs(static_cast<int>(o.dx)));
+  if (2 * R + 1 > LB_WIN)
+    return false;
+  t.R = R;
+  for (size_t o = 0; o < offs.size(); o++)
+  {
+    int row = -1;
+    for (int r = 0; r < t.n_rows; r++)
+      if (t.rows[r].dy == offs[o].dy && t.rows[r].dz == offs[o].dz)
+        row = r;
+    if (row < 0)
+    {
+      if (t.n_rows == LB_MAX_ROWS)
+        return false;
+      row = t.n_rows++;
+      t.rows[row].dy = offs[o].dy;
+      t.rows[row].dz = offs[o].dz;
+      for (auto& x : t.rows[row].o)
+        x = -1;
+    }
+    const int s = offs[o].dx + R;
+    t.rows[row].valid |= static_cast<uint8_t>(1u << s);
+    t.rows[row].o[s] = static_cast<int8_t>(o);
+    auto oct = [](int p) { return ((p & 3) >> 1) | ((((p >> 2) & 3) >> 1) << 1) | (((p >> 4) >> 1) << 2); };
+    unsigned long long all = ~0ull, any = 0ull;
+    bool seen[64] = {};
+    for (int p = 0; p < 64; p++)
+      for (int q = 0; q < 64; q++)
+      {
+        const int bit = oct(p) * 8 + oct(q);
+        const bool is_sure = (sure[o * 64 + p] >> q) & 1ull, is_amb = (amb[o * 64 + p] >> q) & 1ull;
+        if (!is_sure)
+          all &= ~(1ull << bit);
+        if (is_sure || is_amb)
+          any |= 1ull << bit;
+        seen[bit] = true;
+      }
+    (void)seen;
+    t.oct[2 * o] = all;
+    t.oct[2 * o + 1] = any;
+  }
   return true;
 }
 
@@ -754,6 +829,7 @@ int cluster_tables(vofod_handle* h, const GridParams& g, float tol, float cmax, 
     ct = &h->ctab[h->ctab_next];
     h->ctab_next ^= 1;
     ct->valid = false;
+    ct->lds_ok = false;
     std::vector<StencilRow> rows;
     const int r = build_cluster_stencil(g.leaf, tol, cmax, rows, ct->cp);
     if (r != VOFOD_OK)
@@ -800,6 +876,14 @@ int cluster_tables(vofod_handle* h, const GridParams& g, float tol, float cmax, 
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_pair), pair.size()));
         HIPCHK(hipMemcpy(ct->d_pair, pair.data(), pair.size(), hipMemcpyHostToDevice));
       }
+      LbTables lt;
+      ct->lds_ok = build_lds_tables(EdgeClassifier(g.leaf, tol, cmax), offs, sure, amb, lt);
+      if (ct->lds_ok)
+      {
+        if (!ct->d_lbtab)
+          HIPCHK(hipMalloc(reinterpret_cast<void**>(&ct->d_lbtab), sizeof(LbTables)));
+        HIPCHK(hipMemcpy(ct->d_lbtab, &lt, sizeof(LbTables), hipMemcpyHostToDevice));
+      }
     }
     ct->tol = tol;
     ct->cmax = cmax;
@@ -822,7 +906,7 @@ bool want_bricks(const vofod_handle::ClusterTables* ct, const Workspace& ws)
 }
 
 // K7: Euclidean clustering of the frames in `ws`
-int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax)
+int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax, bool allow_lds = false)
 {
   vofod_handle::ClusterTables* ct = nullptr;
   const int rt = cluster_tables(h, g, tol, cmax, &ct);
@@ -833,6 +917,29 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
   {
     BrickParams bp = ct->bp;
     bp.bricks_cap = ws.bricks_cap;
+    // Batches of independent frames: the whole brick graph of a frame is clustered inside one workgroup's LDS
+    // (kernels_brick_lds.h).  VOFOD_BRICK_LDS=0 keeps the global-memory kernels.
+    static const bool lds_on = !(std::getenv("VOFOD_BRICK_LDS") && std::atoi(std::getenv("VOFOD_BRICK_LDS")) == 0);
+    const uint32_t lb_limit = std::getenv("VOFOD_LDS_MAX_BRICKS") ? std::min<uint32_t>(LB_MAX, std::atoi(std::getenv("VOFOD_LDS_MAX_BRICKS"))) : LB_MAX;
+    if (allow_lds && lds_on && ct->lds_ok && !h->lds_ccl_off && !ws.bricks_preset && !g.xcd_map)
+    {
+      static unsigned long long* d_prof = nullptr;
+      if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 16 * 4096));
+      KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), d_prof);
+      if (d_prof)
+      {
+        // VOFOD_LDS_PROF=1 (diagnostics): phase durations of frame 0 from the 100 MHz wall clock
+        unsigned long long t[16];
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(t, d_prof, sizeof(t), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[k_brick_ccl_lds] n %llu hits %llu open %llu | A %.1f B %.1f C %.1f Da %.1f Db %.1f Dc %.1f E %.1f label %.1f us\n", t[11], t[9], t[10], (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[7] - t[3]) * 0.01, (t[8] - t[7]) * 0.01, (t[4] - t[8]) * 0.01,
+                     (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01);
+      }
+      KLAUNCH(h, k_flatten<2>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap);
+      HIPCHK(hipGetLastError());
+      return VOFOD_OK;
+    }
     if (!ws.bricks_preset)
       KLAUNCH(h, k_brick_set, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
     ws.bricks_preset = false;
@@ -1152,7 +1259,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     HIPCHK(hipEventRecord(ev[1], h->stream));
 
   // ---- K7 clusterCloud :932
-  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h));
+  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4);
   if (r != VOFOD_OK)
     return r;
   if (dbg)
@@ -1202,7 +1309,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ws.pending = true;
     ws.job_n = n;
     ws.job_g = g;
-    ws.job_tfs.assign(tfs, tfs + 12 * static_cast<size_t>(n));
+    if (tfs != ws.job_tfs.data())
+      ws.job_tfs.assign(tfs, tfs + 12 * static_cast<size_t>(n));
+    if (scans != ws.job_scans.data())
+      ws.job_scans.assign(scans, scans + n);
     return VOFOD_OK;
   }
   }  // launch part
@@ -1216,6 +1326,15 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   else
     HIPCHK(hipStreamSynchronize(h->stream));
   tr_sync1 = ms_since(t0);
+  for (uint32_t f = 0; f < n; f++)
+    if (ws.h_packed[f].hdr.status == CCL_RETRY_STATUS)
+    {
+      // a frame held more bricks than the LDS clustering kernel takes: nothing of this batch was used (batches never
+      // update the map); the caller runs it again on the global-memory kernels
+      h->lds_ccl_off = true;
+      ws.bitmap_clean = false;
+      return CCL_RETRY_STATUS;
+    }
   if (!no_update)
     h->mapbits_valid = false;
 
