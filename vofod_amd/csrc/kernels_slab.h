@@ -1,0 +1,211 @@
+// Occupancy bitmap built in LDS slabs (gfx950) - the fast form of K4b/K5a/K6-weights for lattices of moderate size.
+//
+// k_setbits marks cells with one global 64-bit atomic per point.  A 128-ring scan at 0.25 m leaves ~40 k points
+// in a lattice of 11 M cells: every atomic is a read-modify-write of a cache line nobody else touches, so the kernel
+// runs at the pace of random 64-byte HBM accesses (measured: 2.7 us per frame, flat in the batch size).  Here
+//   k_key   computes the cell key of every surviving point once and appends it to the frame's key list
+//           (block-level compaction: one global atomic per 8192 points);
+//   k_slab  gives every (frame, 1 Mi-cell slab of the lattice) one workgroup: the slab's bitmap lives in 128 KB of LDS,
+//           the frame's keys (a few hundred KB, L2-resident) are scanned, bits are set with LDS atomics, and the slab
+//           leaves the CU as coalesced 8-byte stores together with its per-256-word popcounts (phase a of the scan).
+//           A point that finds its bit already set is an "extra": only those (points - voxels, ~13 % here) are counted
+//           afterwards; k_emit starts every voxel's weight at 1;
+//   k_count_extras adds the extras to their voxels' weights through the rank lookup.
+// The global bitmap is written densely (zeros included), so it needs no clearing before or after.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_voxelize.h"
+
+namespace vk
+{
+
+constexpr int KEY_THREADS = 1024;
+constexpr int KEY_PPT = 8;  // points per thread
+constexpr int SLAB_THREADS = 1024;
+constexpr uint32_t SLAB_WORDS64 = 16384;              // 64-bit bitmap words per slab = 128 KB of LDS
+constexpr uint32_t SLAB_CELLS = SLAB_WORDS64 * 64u;   // 1 Mi cells
+constexpr int SLAB_EXTRA_CAP = 6144;                  // extras staged in LDS per workgroup
+
+struct SlabArrays
+{
+  uint32_t* keys;    // [F][pt_cap] surviving points' cell keys, unordered
+  uint32_t* extras;  // [F][pt_cap] keys of points that were not the first of their voxel
+  uint32_t* counts;  // [F][2]: n_keys, n_extras
+};
+
+__global__ __launch_bounds__(KEY_THREADS) void k_key(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameArgs& a = args[FRAME];
+  const FrameHdr& h = hdrs[FRAME];
+  if (h.n_in == 0)
+    return;
+  const uint32_t base_pt = BX * KEY_THREADS * KEY_PPT;
+  if (base_pt >= a.n)
+    return;
+  uint32_t key[KEY_PPT];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < KEY_PPT; j++)
+  {
+    const uint32_t i = base_pt + j * KEY_THREADS + threadIdx.x;
+    key[j] = 0xffffffffu;
+    float q[3];
+    if (i < a.n && fetch_point(a, g, i, q))
+    {
+      const uint32_t k = cell_key(h, g, q);
+      if (k < h.n_cells)  // else: rounding artefact outside the lattice, dropped as in k_setbits / k_count
+        key[j] = k;
+    }
+    cnt += key[j] != 0xffffffffu;
+  }
+  // block-level exclusive scan of the per-thread counts
+  __shared__ uint32_t s_wsum[KEY_THREADS / 64];
+  __shared__ uint32_t s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(cnt);
+  if (lane == 63)
+    s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t off = incl - cnt, total = 0;
+  for (int w = 0; w < KEY_THREADS / 64; w++)
+  {
+    const uint32_t x = s_wsum[w];
+    off += w < wave ? x : 0u;
+    total += x;
+  }
+  if (threadIdx.x == 0)
+    s_base = total ? atomicAdd(&sa.counts[2 * FRAME], total) : 0u;
+  __syncthreads();
+  uint32_t* out = sa.keys + static_cast<size_t>(FRAME) * pt_cap + s_base + off;
+#pragma unroll
+  for (int j = 0; j < KEY_PPT; j++)
+    if (key[j] != 0xffffffffu)
+      *out++ = key[j];
+}
+
+__global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, unsigned long long* __restrict__ bitmaps,
+                                                      uint32_t* __restrict__ blocksums, uint32_t nblk_cap)
+{
+  __shared__ uint32_t s_bits[SLAB_WORDS64 * 2];
+  __shared__ uint32_t s_extra[SLAB_EXTRA_CAP];
+  __shared__ uint32_t s_bsum[SLAB_WORDS64 / SCAN_WPB];
+  __shared__ uint32_t s_ne, s_gbase;
+  uint32_t FRAME, SLAB, GX;
+  if (!frame_block(g, FRAME, SLAB, GX))
+    return;
+  (void)GX;
+  const FrameHdr& h = hdrs[FRAME];
+  const uint32_t w_first = SLAB * SLAB_WORDS64;
+  if (w_first >= h.n_words)
+    return;
+  const uint32_t n_w = min(SLAB_WORDS64, h.n_words - w_first);
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (uint32_t i = tid; i < SLAB_WORDS64 * 2; i += SLAB_THREADS)
+    s_bits[i] = 0u;
+  if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB))
+    s_bsum[tid] = 0u;
+  if (tid == 0)
+    s_ne = 0u;
+  __syncthreads();
+  const uint32_t n_keys = sa.counts[2 * FRAME];
+  const uint32_t* keys = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
+  uint32_t* extras = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
+  const uint32_t cell0 = SLAB * SLAB_CELLS;
+  constexpr int KU = 8;
+  const uint32_t n_round = (n_keys + 63u) & ~63u;  // whole waves: the extras are appended with a ballot
+  for (uint32_t i0 = tid; i0 < n_round; i0 += SLAB_THREADS * KU)
+  {
+    uint32_t kv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+    {
+      const uint32_t i = i0 + u * SLAB_THREADS;
+      kv[u] = i < n_keys ? keys[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+    {
+      if (i0 + u * SLAB_THREADS >= n_round)  // wave-uniform
+        break;
+      const uint32_t local = kv[u] - cell0;  // wraps to a huge value for keys below the slab and for the filler
+      bool extra = false;
+      if (kv[u] != 0xffffffffu && local < SLAB_CELLS)
+      {
+        const uint32_t bit = 1u << (local & 31u);
+        extra = (atomicOr(&s_bits[local >> 5], bit) & bit) != 0u;
+      }
+      const unsigned long long m = __ballot(extra);
+      if (m)
+      {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&s_ne, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader);
+        if (extra)
+        {
+          const uint32_t p = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (p < SLAB_EXTRA_CAP)
+            s_extra[p] = kv[u];
+          else
+            extras[atomicAdd(&sa.counts[2 * FRAME + 1], 1u)] = kv[u];  // staging area full: straight to the list
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // the staged extras leave with one reservation per workgroup
+  const uint32_t ne = min(s_ne, static_cast<uint32_t>(SLAB_EXTRA_CAP));
+  if (tid == 0)
+    s_gbase = ne ? atomicAdd(&sa.counts[2 * FRAME + 1], ne) : 0u;
+  // the slab: coalesced 8-byte stores + popcounts per 256-word block (phase a of the rank scan)
+  unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2) + w_first;
+  const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(s_bits);
+  for (uint32_t w = tid; w < SLAB_WORDS64; w += SLAB_THREADS)
+  {
+    const unsigned long long v = s64[w];
+    if (w < n_w)
+      bm[w] = v;
+    uint32_t c = __popcll(v);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
+      c += __shfl_xor(c, s);
+    if (lane == 0 && c)
+      atomicAdd(&s_bsum[w / SCAN_WPB], c);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
+    extras[s_gbase + i] = s_extra[i];
+  const uint32_t blk0 = w_first / SCAN_WPB;
+  if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB) && static_cast<uint32_t>(tid) * SCAN_WPB < n_w)
+    blocksums[static_cast<size_t>(FRAME) * nblk_cap + blk0 + tid] = s_bsum[tid];
+}
+
+// weights: every voxel starts at 1 (k_emit); each extra point adds 1 to its voxel
+__global__ __launch_bounds__(256) void k_count_extras(const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, const unsigned long long* __restrict__ bitmaps,
+                                                      const uint32_t* __restrict__ wprefix_all, VoxelArrays va_all)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  const FrameHdr& h = hdrs[FRAME];
+  if (h.V == 0)
+    return;
+  const uint32_t ne = sa.counts[2 * FRAME + 1];
+  const uint32_t* extras = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
+  const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  for (uint32_t i = BX * blockDim.x + threadIdx.x; i < ne; i += GX * blockDim.x)
+  {
+    const uint32_t r = rank_of(bm, wprefix, extras[i]);
+    atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[r].w), 1u);
+  }
+}
+
+}  // namespace vk

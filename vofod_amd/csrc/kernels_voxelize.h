@@ -500,7 +500,7 @@ __device__ __forceinline__ void brick_append(FrameHdr& h, const BrickArrays& ba,
 // thread then produces output slots t, t+256, ... (locating the owning word by binary search), so the
 // voxel records leave the CU as coalesced 16-byte-per-lane stores regardless of how the set bits cluster.
 __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
-                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all, const BrickParams bp, BrickArrays ba_all, int brick_on)
+                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all, const BrickParams bp, BrickArrays ba_all, int brick_on, uint32_t init_count)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
       p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
       p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
       p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
-      p.w = __uint_as_float(0u);
+      p.w = __uint_as_float(init_count);  // weight: 0 when k_count adds every point, 1 when only the extras are added
       va.pts[rank] = p;
       va.key[rank] = key;
       va.parent[rank] = rank;

@@ -24,6 +24,7 @@
 #include "kernels_classify.h"
 #include "kernels_cluster.h"
 #include "kernels_raycast.h"
+#include "kernels_slab.h"
 #include "kernels_voxelize.h"
 
 using namespace vk;
@@ -173,6 +174,7 @@ struct Workspace
   ClusterRec* d_table = nullptr;
   CandMember* d_cand = nullptr;
   uint32_t* d_ptrank = nullptr;
+  SlabArrays sa{};  // key list / extras of the LDS-slab voxelisation (keys share d_ptrank's storage)
   float* d_stage = nullptr;  // F * pt_cap * 5 words: x, y, z, intensity, range of host-resident inputs
   PackedFrame* d_packed = nullptr;
   PackedFrame* h_packed = nullptr;  // pinned
@@ -189,7 +191,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, d_stage, d_packed};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -249,6 +251,9 @@ struct Workspace
     WS_ALLOC(d_table, sizeof(ClusterRec) * FV);
     WS_ALLOC(d_cand, sizeof(CandMember) * FV);
     WS_ALLOC(d_ptrank, sizeof(uint32_t) * static_cast<size_t>(F) * pt_cap);
+    WS_ALLOC(sa.extras, sizeof(uint32_t) * static_cast<size_t>(F) * pt_cap);
+    WS_ALLOC(sa.counts, sizeof(uint32_t) * 2 * F);
+    sa.keys = d_ptrank;
     WS_ALLOC(d_stage, sizeof(float) * 5 * static_cast<size_t>(F) * pt_cap);
     WS_ALLOC(d_packed, sizeof(PackedFrame) * F);
 #undef WS_ALLOC
@@ -787,13 +792,33 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
+  // Lattices of at most SLAB_MAX slabs of 1 Mi cells: the bitmap is built slab by slab in LDS (kernels_slab.h).
+  // VOFOD_SLABS=0 keeps the global-atomic kernels (also used for the counted grid, which needs every point's rank).
+  static const bool slabs_on = !(std::getenv("VOFOD_SLABS") && std::atoi(std::getenv("VOFOD_SLABS")) == 0);
+  constexpr uint32_t SLAB_MAX = 32;
+  const uint32_t n_slabs = (ws.words_cap + SLAB_WORDS64 - 1) / SLAB_WORDS64;
+  if (slabs_on && !want_ptrank && !bricks && n_slabs <= SLAB_MAX && !g.xcd_map)
+  {
+    if (!ws.bitmap_clean)  // words beyond this batch's lattices must read as zero (neighbour windows run into the padding)
+      HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * ws.F * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
+    HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
+    const uint32_t gk = std::max(1u, (max_pts + KEY_THREADS * KEY_PPT - 1) / (KEY_THREADS * KEY_PPT));
+    KLAUNCH(h, k_key, fgrid(g, gk), dim3(KEY_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
+    KLAUNCH(h, k_slab, fgrid(g, n_slabs), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+    ws.bitmap_clean = false;
+    KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
+    KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u);
+    KLAUNCH(h, k_count_extras, fgrid(g, 8), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
+    HIPCHK(hipGetLastError());
+    return VOFOD_OK;
+  }
   if (!ws.bitmap_clean)
     HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * ws.F * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
   ws.bitmap_clean = false;  // set again by whoever runs the clearing pass
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, 0u);
   KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
@@ -811,7 +836,7 @@ int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, ui
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, 0u);
   KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
