@@ -473,7 +473,7 @@ void vofod_destroy(vofod_handle* h)
     w.release();
   h->aux.release();
   h->sepws.release();
-  void* ptrs[] = {h->d_map, h->d_flags, h->d_ray, h->d_mapbits, h->d_counter, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_rows, h->d_crows, h->d_boxstage, h->d_idxstage,
+  void* ptrs[] = {h->d_map, h->d_flags, h->d_ray, h->d_mapbits, h->d_mapclose, h->d_counter, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_rows, h->d_crows, h->d_boxstage, h->d_idxstage,
                   h->sep.d_tbits, h->sep.d_tpop, h->sep.d_tprefix, h->sep.d_bsum, h->sep.d_px, h->sep.d_py, h->sep.d_pz, h->sep.d_pi, h->sep.d_sure, h->sep.d_sure_pre,
                   h->sep.d_vcnt, h->sep.d_first, h->sep.d_nsure, h->sep.d_offsets, h->sep.d_small};
   for (void* p : ptrs)
@@ -571,6 +571,7 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_ray), M * sizeof(float)));
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_mapbits), ((M + 63) / 64 + 2) * sizeof(unsigned long long)));
   CREATE_CHK(hipMemset(h->d_mapbits, 0, ((M + 63) / 64 + 2) * sizeof(unsigned long long)));
+  CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_mapclose), ((M + 63) / 64 + 2) * sizeof(unsigned long long)));
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_counter), 8 * sizeof(unsigned long long)));
   CREATE_CHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counter), 8 * sizeof(unsigned long long)));
   CREATE_CHK(hipMalloc(reinterpret_cast<void**>(&h->d_bgcount), 8 * MB_SLOTS * sizeof(unsigned long long)));

@@ -422,9 +422,72 @@ __device__ __forceinline__ bool close_row_hit(const MapGeom& mg, const unsigned 
   return win != 0ull;
 }
 
+// hasCloseTo for every cell of the map at once: out bit = OR of the occupancy image over the cell's stencil, i.e. the
+// image dilated by the half-open cube of voxel_map.cpp:384-393.  Worth its cost (one pass of n_rows window tests per 64
+// cells) when the map stays unchanged over many frames (batches): k_closefar then answers a voxel with one bit.
+// One thread per chunk of 64 x-cells of a map row; `out` must be zero on entry.
+__global__ __launch_bounds__(256) void k_dilate(const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows, const unsigned long long* __restrict__ mapbits,
+                                                unsigned long long* __restrict__ out)
+{
+  const uint32_t cx = (mg.sx + 63) >> 6;
+  const uint64_t c = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= static_cast<uint64_t>(mg.sz) * mg.sy * cx)
+    return;
+  const int z = static_cast<int>(c / (static_cast<uint64_t>(mg.sy) * cx));
+  const uint32_t rem = static_cast<uint32_t>(c - static_cast<uint64_t>(z) * mg.sy * cx);
+  const int y = rem / cx;
+  const int x0 = static_cast<int>(rem - y * cx) * 64;
+  const int nx = min(64, mg.sx - x0);
+  const int xb = x0 - 32;  // the 128-bit input window starts 32 cells left of the chunk (|dx| <= MAX_R = 31)
+  unsigned long long acc = 0ull;
+  for (int r = 0; r < cp.n_rows; r++)
+  {
+    const CloseRow row = rows[r];
+    const int yy = y + row.dy, zz = z + row.dz;
+    if (yy < 0 || yy >= mg.sy || zz < 0 || zz >= mg.sz)
+      continue;
+    const int xs = max(xb, 0), shiftin = xs - xb;  // 0 or 32
+    const uint64_t P = (static_cast<uint64_t>(zz) * mg.sy + yy) * mg.sx + xs;
+    const uint64_t wi = P >> 6;
+    const int sh = P & 63;
+    const unsigned long long w0 = mapbits[wi], w1 = mapbits[wi + 1], w2 = mapbits[wi + 2];
+    unsigned long long lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    unsigned long long hi = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+    // cells at or beyond the end of the map row read as empty
+    const int valid = mg.sx - xs;  // bits of (hi:lo) that belong to this row
+    if (valid < 64)
+    {
+      lo &= (1ull << valid) - 1ull;
+      hi = 0ull;
+    }
+    else if (valid < 128)
+      hi &= (valid == 64) ? 0ull : ((1ull << (valid - 64)) - 1ull);
+    if (shiftin)
+    {
+      hi = (hi << 32) | (lo >> 32);
+      lo <<= 32;
+    }
+    // out bit i (x = x0 + i = xb + 32 + i) |= in bit (32 + i + dx) for dx in [x_lo, x_hi]
+    for (int dx = row.x_lo; dx <= row.x_hi; dx++)
+    {
+      const int s = 32 + dx;  // 1..63
+      acc |= (lo >> s) | (hi << (64 - s));
+    }
+  }
+  if (nx < 64)
+    acc &= (1ull << nx) - 1ull;
+  if (!acc)
+    return;
+  const uint64_t L = (static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + x0;
+  const int so = L & 63;
+  atomicOr(&out[L >> 6], acc << so);
+  if (so && (acc >> (64 - so)))
+    atomicOr(&out[(L >> 6) + 1], acc >> (64 - so));
+}
+
 __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows,
                                                   const FrameHdr* hdrs, const unsigned long long* __restrict__ mapbits, VoxelArrays va_all,
-                                                  const uint32_t* labels_all)
+                                                  const uint32_t* labels_all, const unsigned long long* __restrict__ mapclose)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
@@ -460,7 +523,14 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
     ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
     oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
     oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
-    if (cp.n_rows > 0 && close_row_hit(mg, mapbits, rows[0], ox, oy, oz))  // rows[0] is (dy,dz) = (0,0): nearest first
+    if (mapclose && ox >= 0 && ox < mg.sx && oy >= 0 && oy < mg.sy && oz >= 0 && oz < mg.sz)
+    {
+      // the dilated image (k_dilate) holds the whole answer for cells of the map
+      const uint64_t L = (static_cast<uint64_t>(oz) * mg.sy + oy) * mg.sx + ox;
+      if ((mapclose[L >> 6] >> (L & 63)) & 1ull)
+        hit_root = root;
+    }
+    else if (cp.n_rows > 0 && close_row_hit(mg, mapbits, rows[0], ox, oy, oz))  // rows[0] is (dy,dz) = (0,0): nearest first
       hit_root = root;
     else
       undecided = true;

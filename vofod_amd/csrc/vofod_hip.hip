@@ -310,6 +310,9 @@ struct vofod_handle
   vt::Geom hg{};
   float *d_map = nullptr, *d_flags = nullptr, *d_ray = nullptr;
   unsigned long long* d_mapbits = nullptr;
+  unsigned long long* d_mapclose = nullptr;  // d_mapbits dilated by hasCloseTo's stencil (k_dilate), valid while gens match
+  uint64_t mapbits_gen = 0, mapclose_gen = ~0ull;
+  float mapclose_dist = -1.0f;
   unsigned long long* d_counter = nullptr;  // scratch words
   unsigned long long *d_bgcount = nullptr, *h_bgcount = nullptr;  // MB_SLOTS partial nVoxelsOver counters (64 B apart); host pinned copy
   bool bgcount_fresh = false;
@@ -1003,9 +1006,25 @@ int ensure_mapbits(vofod_handle* h, float thr)
   KLAUNCH(h, k_mapbits, dim3(1024), dim3(256), h->d_map, h->mg.n, thr, h->d_mapbits, h->d_bgcount);
   HIPCHK(hipMemcpyAsync(h->h_bgcount, h->d_bgcount, sizeof(unsigned long long) * 8 * MB_SLOTS, hipMemcpyDeviceToHost, h->stream));
   h->bgcount_fresh = true;
+  h->mapbits_gen++;
   h->mapbits_valid = true;
   h->mapbits_thr = thr;
   return VOFOD_OK;  // h_counter is valid after the next stream sync
+}
+
+// the dilated occupancy image for read-only batches (see k_dilate); call after ensure_mapbits and the close-row upload
+int ensure_mapclose(vofod_handle* h, const CloseParams& cpar)
+{
+  if (h->mapclose_gen == h->mapbits_gen && h->mapclose_dist == h->closetab.max_dist)
+    return VOFOD_OK;
+  const size_t words = (h->mg.n + 63) / 64 + 2;
+  HIPCHK(hipMemsetAsync(h->d_mapclose, 0, words * sizeof(unsigned long long), h->stream));
+  const uint64_t chunks = static_cast<uint64_t>(h->mg.sz) * h->mg.sy * ((h->mg.sx + 63) / 64);
+  KLAUNCH(h, k_dilate, dim3(static_cast<uint32_t>((chunks + 255) / 256)), dim3(256), h->mg, cpar, h->d_crows, h->d_mapbits, h->d_mapclose);
+  HIPCHK(hipStreamSynchronize(h->stream));  // other chains read it from their own streams
+  h->mapclose_gen = h->mapbits_gen;
+  h->mapclose_dist = h->closetab.max_dist;
+  return VOFOD_OK;
 }
 
 float map_cmax(const vofod_handle* h)
@@ -1310,7 +1329,16 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   }
   CloseParams cpar{h->closetab.n_rows, thr_new};
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
-  KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels);
+  // read-only batches: the map's dilated image answers hasCloseTo with one bit per voxel (VOFOD_DILATE=0: stencil sweep)
+  static const bool dilate_on = !(std::getenv("VOFOD_DILATE") && std::atoi(std::getenv("VOFOD_DILATE")) == 0);
+  const bool use_dilated = dilate_on && no_update && n >= 4;
+  if (use_dilated)
+  {
+    r = ensure_mapclose(h, cpar);
+    if (r != VOFOD_OK)
+      return r;
+  }
+  KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels, use_dilated ? h->d_mapclose : nullptr);
   if (dbg)
     HIPCHK(hipEventRecord(ev[3], h->stream));
 
