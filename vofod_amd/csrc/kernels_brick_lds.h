@@ -579,6 +579,18 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
     if (my_root[r] != 0xffffffffu)
       atomicMin(&s_cmin[my_root[r]], my_min[r]);
   __syncthreads();
+  // the roots' statistics slots (size, lattice box, close flag): k_emit left them to this kernel (lean emission)
+#pragma unroll
+  for (int r = 0; r < LB_MAX / LB_THREADS; r++)
+    if (my_root[r] == static_cast<uint32_t>(r * LB_THREADS + tid))
+    {
+      const uint32_t label = s_cmin[my_root[r]];
+      va.csize[label] = 0;
+      va.cclose[label] = 0;
+      int* cb = &va.cbox[6 * label];
+      cb[0] = cb[1] = cb[2] = 0x7fffffff;
+      cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+    }
   LB_STAMP(5);
   for (uint32_t v0 = tid; v0 < V; v0 += LB_THREADS * VU)
   {

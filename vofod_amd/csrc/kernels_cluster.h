@@ -183,12 +183,33 @@ __global__ __launch_bounds__(256) void k_union(const GridParams g, const Cluster
 }
 
 // Flatten the forest (label = root = smallest member) and accumulate per-cluster size and lattice AABB.
+// one (dy,dz) row of hasCloseTo's stencil against the occupancy image
+__device__ __forceinline__ bool close_row_hit(const MapGeom& mg, const unsigned long long* __restrict__ mapbits, const CloseRow row, int ox, int oy, int oz)
+{
+  const int y = oy + row.dy, z = oz + row.dz;
+  if (y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
+    return false;
+  const int lo = max(ox + row.x_lo, 0), hi = min(ox + row.x_hi, mg.sx - 1);
+  if (lo > hi)
+    return false;
+  const uint64_t L = (static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + lo;
+  const int nbits = hi - lo + 1;
+  const uint64_t wi = L >> 6;
+  const int sh = L & 63;
+  unsigned long long win = mapbits[wi] >> sh;
+  if (sh + nbits > 64)
+    win |= mapbits[wi + 1] << (64 - sh);
+  win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+  return win != 0ull;
+}
+
 // Cluster statistics are pre-aggregated per wave (shuffles) and per block (a small LDS hash keyed by root)
 // so that the one giant ground cluster does not serialise thousands of global atomics on seven addresses.
 constexpr int FL_SLOTS = 64;
 template <int SRC>
 __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const FrameHdr* hdrs, VoxelArrays va_all, uint32_t* labels_all, const BrickArrays ba_all,
-                                                 uint32_t bricks_cap)
+                                                 uint32_t bricks_cap, const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
+                                                 const CloseRow* __restrict__ crows, int n_crows)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
@@ -242,6 +263,34 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
     }
     if (SRC != 2)
       labels[v] = root;
+  }
+  // hasCloseTo through the dilated occupancy image (k_dilate), when the caller has one: the voxel centre is rebuilt with
+  // k_emit's expression, its map cell looked up, and one flag store per run of equal roots marks the cluster close
+  if (mapclose)
+  {
+    uint32_t hit_root = 0xffffffffu;
+    if (active)
+    {
+      const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ijk[0]), 0.5f), g.leaf[0]), h.offset[0]);
+      const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ijk[1]), 0.5f), g.leaf[1]), h.offset[1]);
+      const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(ijk[2]), 0.5f), g.leaf[2]), h.offset[2]);
+      const int ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
+      const int oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
+      const int oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
+      if (ox >= 0 && ox < mg.sx && oy >= 0 && oy < mg.sy && oz >= 0 && oz < mg.sz)
+      {
+        const uint64_t L = (static_cast<uint64_t>(oz) * mg.sy + oy) * mg.sx + ox;
+        if ((mapclose[L >> 6] >> (L & 63)) & 1ull)
+          hit_root = root;
+      }
+      else  // a centre outside the map (a point on the far face of the operation area): the stencil sweep, clipped to the map
+        for (int r = 0; r < n_crows && hit_root == 0xffffffffu; r++)
+          if (close_row_hit(mg, mapbits, crows[r], ox, oy, oz))
+            hit_root = root;
+    }
+    int end;
+    if (run_heads(hit_root, static_cast<int>(threadIdx.x & 63), end) && hit_root != 0xffffffffu)
+      __hip_atomic_store(&va.cclose[hit_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // wave level: reduce the wave's leading cluster with shuffles
   const unsigned long long m_active = __ballot(active);
@@ -403,25 +452,6 @@ __global__ __launch_bounds__(256) void k_mapbits(const float* __restrict__ map, 
 // voxel hits there).  Phase B: the voxels still undecided are taken one at a time by the whole wave, each
 // lane testing rows lane, lane+64, ... of the stencil, so a true negative costs n_rows/64 row tests per
 // lane instead of n_rows serial ones and divergence does not hold finished lanes hostage.
-__device__ __forceinline__ bool close_row_hit(const MapGeom& mg, const unsigned long long* __restrict__ mapbits, const CloseRow row, int ox, int oy, int oz)
-{
-  const int y = oy + row.dy, z = oz + row.dz;
-  if (y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
-    return false;
-  const int lo = max(ox + row.x_lo, 0), hi = min(ox + row.x_hi, mg.sx - 1);
-  if (lo > hi)
-    return false;
-  const uint64_t L = (static_cast<uint64_t>(z) * mg.sy + y) * mg.sx + lo;
-  const int nbits = hi - lo + 1;
-  const uint64_t wi = L >> 6;
-  const int sh = L & 63;
-  unsigned long long win = mapbits[wi] >> sh;
-  if (sh + nbits > 64)
-    win |= mapbits[wi + 1] << (64 - sh);
-  win &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
-  return win != 0ull;
-}
-
 // hasCloseTo for every cell of the map at once: out bit = OR of the occupancy image over the cell's stencil, i.e. the
 // image dilated by the half-open cube of voxel_map.cpp:384-393.  Worth its cost (one pass of n_rows window tests per 64
 // cells) when the map stays unchanged over many frames (batches): k_closefar then answers a voxel with one bit.

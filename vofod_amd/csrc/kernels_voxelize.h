@@ -602,16 +602,19 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
       p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
       p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
       p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
-      p.w = __uint_as_float(init_count);  // weight: 0 when k_count adds every point, 1 when only the extras are added
+      p.w = __uint_as_float(init_count & 0x7fffffffu);  // weight: 0 when k_count adds every point, 1 when only the extras are added
       va.pts[rank] = p;
       va.key[rank] = key;
-      va.parent[rank] = rank;
-      va.csize[rank] = 0;
-      va.cclose[rank] = 0;
       va.bb[rank] = (static_cast<uint32_t>(((k2 >> 2) * ((h.div_b[1] + 3) >> 2) + (k1 >> 2)) * ((h.div_b[0] + 3) >> 2) + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
-      int* cb = &va.cbox[6 * rank];
-      cb[0] = cb[1] = cb[2] = 0x7fffffff;
-      cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+      if (!(init_count & 0x80000000u))  // lean emission: the LDS clustering kernel initialises the slots of the roots only
+      {
+        va.parent[rank] = rank;
+        va.csize[rank] = 0;
+        va.cclose[rank] = 0;
+        int* cb = &va.cbox[6 * rank];
+        cb[0] = cb[1] = cb[2] = 0x7fffffff;
+        cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+      }
       if (brick_on)
         first = brick_mark(h, ba, k0, k1, k2, rank, brick);
     }

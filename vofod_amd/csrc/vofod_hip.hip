@@ -181,6 +181,8 @@ struct Workspace
   std::vector<FrameArgs> h_args;
   bool bricks_preset = false;  // k_emit already registered the voxels in their bricks (fused brick_set)
   std::vector<vofod_scan> job_scans;  // the submitted batch (re-run when the LDS clustering kernel overflows)
+  bool lean_emit = false;       // k_emit skipped the per-root slots: launch_cluster must run the LDS clustering kernel
+  bool closefar_fused = false;  // launch_cluster answered hasCloseTo as well (dilated image inside k_flatten)
   bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
   // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
   bool pending = false;
@@ -776,7 +778,8 @@ inline dim3 fgrid(const GridParams& g, uint32_t gx)
 }
 
 // kernel chain K1-K6 over frames [0,n): bbox -> lattice -> occupancy bitmap -> ranks -> weighted cloud
-int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank, bool two_phase, const BrickParams* bricks = nullptr)
+int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank, bool two_phase, const BrickParams* bricks = nullptr,
+                    bool lean_hint = false)
 {
   BrickParams bpv{};
   if (bricks)
@@ -787,6 +790,9 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   // measured on MI355X (32 frames, 0.25 m): the XCD-aware mapping is 5-9 % slower than plain dealing, so it is opt-in
   static const bool xcd_on = std::getenv("VOFOD_XCD_MAP") && std::atoi(std::getenv("VOFOD_XCD_MAP")) == 1;
   g.xcd_map = (n >= 8 && xcd_on) ? 1u : 0u;
+  // lean emission: the LDS clustering kernel will follow and initialises the per-root slots itself (see plan_lds_ccl)
+  ws.lean_emit = lean_hint && !bricks && !g.xcd_map && !two_phase;
+  const uint32_t lean_bit = ws.lean_emit ? 0x80000000u : 0u;
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs);
@@ -810,7 +816,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     KLAUNCH(h, k_slab, fgrid(g, n_slabs), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
     ws.bitmap_clean = false;
     KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-    KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u);
+    KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit);
     KLAUNCH(h, k_count_extras, fgrid(g, 8), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
     HIPCHK(hipGetLastError());
     return VOFOD_OK;
@@ -821,7 +827,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, 0u);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, lean_bit);
   KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
@@ -933,9 +939,18 @@ bool want_bricks(const vofod_handle::ClusterTables* ct, const Workspace& ws)
   return ct->brick_ok && ws.bricks_cap > 0;
 }
 
-// K7: Euclidean clustering of the frames in `ws`
-int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax, bool allow_lds = false)
+// Will launch_cluster run the LDS-resident brick clustering (kernels_brick_lds.h) for this batch?  k_emit then leaves the
+// per-root statistics slots to that kernel.  VOFOD_BRICK_LDS=0 keeps the global-memory kernels.
+bool plan_lds_ccl(const vofod_handle* h, const vofod_handle::ClusterTables* ct, const Workspace& ws, bool allow_lds)
 {
+  static const bool lds_on = !(std::getenv("VOFOD_BRICK_LDS") && std::atoi(std::getenv("VOFOD_BRICK_LDS")) == 0);
+  return allow_lds && lds_on && want_bricks(ct, ws) && ct->lds_ok && !h->lds_ccl_off;
+}
+
+// K7: Euclidean clustering of the frames in `ws`
+int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax, bool allow_lds = false, const unsigned long long* mapclose = nullptr)
+{
+  ws.closefar_fused = false;
   vofod_handle::ClusterTables* ct = nullptr;
   const int rt = cluster_tables(h, g, tol, cmax, &ct);
   if (rt != VOFOD_OK)
@@ -947,10 +962,11 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     bp.bricks_cap = ws.bricks_cap;
     // Batches of independent frames: the whole brick graph of a frame is clustered inside one workgroup's LDS
     // (kernels_brick_lds.h).  VOFOD_BRICK_LDS=0 keeps the global-memory kernels.
-    static const bool lds_on = !(std::getenv("VOFOD_BRICK_LDS") && std::atoi(std::getenv("VOFOD_BRICK_LDS")) == 0);
     const uint32_t lb_limit = std::getenv("VOFOD_LDS_MAX_BRICKS") ? std::min<uint32_t>(LB_MAX, std::atoi(std::getenv("VOFOD_LDS_MAX_BRICKS"))) : LB_MAX;
-    if (allow_lds && lds_on && ct->lds_ok && !h->lds_ccl_off && !ws.bricks_preset && !g.xcd_map)
+    if (ws.lean_emit)
     {
+      (void)allow_lds;
+      ws.lean_emit = false;
       static unsigned long long* d_prof = nullptr;
       if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 16 * 4096));
@@ -964,7 +980,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
         std::fprintf(stderr, "[k_brick_ccl_lds] n %llu hits %llu open %llu | A %.1f B %.1f C %.1f Da %.1f Db %.1f Dc %.1f E %.1f label %.1f us\n", t[11], t[9], t[10], (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[7] - t[3]) * 0.01, (t[8] - t[7]) * 0.01, (t[4] - t[8]) * 0.01,
                      (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01);
       }
-      KLAUNCH(h, k_flatten<2>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap);
+      KLAUNCH(h, k_flatten<2>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap, h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows);
+      ws.closefar_fused = mapclose != nullptr;  // hasCloseTo answered inside the flatten kernel
       HIPCHK(hipGetLastError());
       return VOFOD_OK;
     }
@@ -985,13 +1002,13 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     else
       KLAUNCH(h, k_brick_union<1>, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
     KLAUNCH(h, k_brick_root, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.ba, ws.d_bitmaps, ws.d_wprefix);
-    KLAUNCH(h, k_flatten<1>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap);
+    KLAUNCH(h, k_flatten<1>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap, h->mg, nullptr, nullptr, nullptr, 0);
     KLAUNCH(h, k_brick_clear, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.ba);
   }
   else
   {
     KLAUNCH(h, k_union<2>, fgrid(g, gv), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
-    KLAUNCH(h, k_flatten<0>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, 0u);
+    KLAUNCH(h, k_flatten<0>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, 0u, h->mg, nullptr, nullptr, nullptr, 0);
   }
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
@@ -1282,34 +1299,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   float align_center[3];
   h->hg.idxToCoord(zero, align_center);  // :664
   fill_grid_params(h, g, leaf, true, align_center, ws);
-  if (dbg)
-    HIPCHK(hipEventRecord(ev[0], h->stream));
-  {
-    // the clustering family is known up front, so the emission kernel can register the voxels in their bricks
-    vofod_handle::ClusterTables* ct = nullptr;
-    r = cluster_tables(h, g, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), &ct);
-    if (r != VOFOD_OK)
-      return r;
-    g.sparse_prefix = want_bricks(ct, ws) ? 1u : 0u;
-    BrickParams bp = ct->bp;
-    // Fusing the brick registration into k_emit was measured slower (194 us vs 96 + 50 us for 32 frames: the returning
-    // atomicOr sits inside the load-balanced emission loop), so it stays a kernel of its own unless VOFOD_FUSE_BRICKS=1.
-    static const bool fuse = std::getenv("VOFOD_FUSE_BRICKS") && std::atoi(std::getenv("VOFOD_FUSE_BRICKS")) == 1;
-    r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false, (fuse && want_bricks(ct, ws)) ? &bp : nullptr);
-  }
-  if (r != VOFOD_OK)
-    return r;
-  if (dbg)
-    HIPCHK(hipEventRecord(ev[1], h->stream));
-
-  // ---- K7 clusterCloud :932
-  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4);
-  if (r != VOFOD_OK)
-    return r;
-  if (dbg)
-    HIPCHK(hipEventRecord(ev[2], h->stream));
-
-  // ---- K8/K9 findCloseFarClusters :703-750
+  // ---- tables and map images of K8/K9 (findCloseFarClusters :703-750): independent of the frames, prepared first
   r = ensure_mapbits(h, thr_new);
   if (r != VOFOD_OK)
     return r;
@@ -1328,7 +1318,6 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     h->closetab.n_rows = static_cast<int>(crows.size());
   }
   CloseParams cpar{h->closetab.n_rows, thr_new};
-  const uint32_t gv = (ws.vox_cap + 255u) / 256u;
   // read-only batches: the map's dilated image answers hasCloseTo with one bit per voxel (VOFOD_DILATE=0: stencil sweep)
   static const bool dilate_on = !(std::getenv("VOFOD_DILATE") && std::atoi(std::getenv("VOFOD_DILATE")) == 0);
   const bool use_dilated = dilate_on && no_update && n >= 4;
@@ -1338,7 +1327,38 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     if (r != VOFOD_OK)
       return r;
   }
-  KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels, use_dilated ? h->d_mapclose : nullptr);
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[0], h->stream));
+  {
+    // the clustering family is known up front, so the emission kernel can register the voxels in their bricks
+    vofod_handle::ClusterTables* ct = nullptr;
+    r = cluster_tables(h, g, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), &ct);
+    if (r != VOFOD_OK)
+      return r;
+    g.sparse_prefix = want_bricks(ct, ws) ? 1u : 0u;
+    BrickParams bp = ct->bp;
+    // Fusing the brick registration into k_emit was measured slower (194 us vs 96 + 50 us for 32 frames: the returning
+    // atomicOr sits inside the load-balanced emission loop), so it stays a kernel of its own unless VOFOD_FUSE_BRICKS=1.
+    static const bool fuse = std::getenv("VOFOD_FUSE_BRICKS") && std::atoi(std::getenv("VOFOD_FUSE_BRICKS")) == 1;
+    r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false, (fuse && want_bricks(ct, ws)) ? &bp : nullptr, plan_lds_ccl(h, ct, ws, no_update && n >= 4));
+  }
+  if (r != VOFOD_OK)
+    return r;
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[1], h->stream));
+
+  // ---- K7 clusterCloud :932
+  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr);
+  if (r != VOFOD_OK)
+    return r;
+  if (dbg)
+    HIPCHK(hipEventRecord(ev[2], h->stream));
+
+  // ---- K8/K9 findCloseFarClusters :703-750 (tables and images were prepared before the chain was enqueued)
+  const uint32_t gv = (ws.vox_cap + 255u) / 256u;
+  if (!ws.closefar_fused)
+    KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels, use_dilated ? h->d_mapclose : nullptr);
+  ws.closefar_fused = false;
   if (dbg)
     HIPCHK(hipEventRecord(ev[3], h->stream));
 
