@@ -88,6 +88,11 @@ __global__ __launch_bounds__(KEY_THREADS) void k_key(const FrameArgs* args, cons
       *out++ = key[j];
 }
 
+constexpr int SLAB_KR = 48;  // keys a lane keeps in registers across the slabs of its workgroup
+
+// One workgroup serves the slabs GI, GI + G, ... of a frame.  The frame's keys are fetched once into registers (48 Ki
+// keys; a longer list is re-read per slab), so with G = 1 (large batches: one workgroup per frame keeps every CU busy)
+// the key list crosses the memory system once instead of once per slab.
 __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, unsigned long long* __restrict__ bitmaps,
                                                       uint32_t* __restrict__ blocksums, uint32_t nblk_cap)
 {
@@ -95,50 +100,47 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const
   __shared__ uint32_t s_extra[SLAB_EXTRA_CAP];
   __shared__ uint32_t s_bsum[SLAB_WORDS64 / SCAN_WPB];
   __shared__ uint32_t s_ne, s_gbase;
-  uint32_t FRAME, SLAB, GX;
-  if (!frame_block(g, FRAME, SLAB, GX))
+  uint32_t FRAME, GI, G;
+  if (!frame_block(g, FRAME, GI, G))
     return;
-  (void)GX;
   const FrameHdr& h = hdrs[FRAME];
-  const uint32_t w_first = SLAB * SLAB_WORDS64;
-  if (w_first >= h.n_words)
+  const uint32_t n_slabs = (h.n_words + SLAB_WORDS64 - 1) / SLAB_WORDS64;
+  if (GI >= n_slabs)
     return;
-  const uint32_t n_w = min(SLAB_WORDS64, h.n_words - w_first);
   const int tid = threadIdx.x, lane = tid & 63;
-  for (uint32_t i = tid; i < SLAB_WORDS64 * 2; i += SLAB_THREADS)
-    s_bits[i] = 0u;
-  if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB))
-    s_bsum[tid] = 0u;
-  if (tid == 0)
-    s_ne = 0u;
-  __syncthreads();
   const uint32_t n_keys = sa.counts[2 * FRAME];
   const uint32_t* keys = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
   uint32_t* extras = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
-  const uint32_t cell0 = SLAB * SLAB_CELLS;
-  constexpr int KU = 8;
   const uint32_t n_round = (n_keys + 63u) & ~63u;  // whole waves: the extras are appended with a ballot
-  for (uint32_t i0 = tid; i0 < n_round; i0 += SLAB_THREADS * KU)
+  uint32_t kreg[SLAB_KR];
+#pragma unroll
+  for (int j = 0; j < SLAB_KR; j++)
   {
-    uint32_t kv[KU];
-#pragma unroll
-    for (int u = 0; u < KU; u++)
-    {
-      const uint32_t i = i0 + u * SLAB_THREADS;
-      kv[u] = i < n_keys ? keys[i] : 0xffffffffu;
-    }
-#pragma unroll
-    for (int u = 0; u < KU; u++)
-    {
-      if (i0 + u * SLAB_THREADS >= n_round)  // wave-uniform
-        break;
-      const uint32_t local = kv[u] - cell0;  // wraps to a huge value for keys below the slab and for the filler
-      bool extra = false;
-      if (kv[u] != 0xffffffffu && local < SLAB_CELLS)
-      {
-        const uint32_t bit = 1u << (local & 31u);
-        extra = (atomicOr(&s_bits[local >> 5], bit) & bit) != 0u;
-      }
+    const uint32_t i = j * SLAB_THREADS + tid;
+    kreg[j] = i < n_keys ? keys[i] : 0xffffffffu;
+  }
+  for (uint32_t SLAB = GI; SLAB < n_slabs; SLAB += G)
+  {
+    const uint32_t w_first = SLAB * SLAB_WORDS64;
+    const uint32_t n_w = min(SLAB_WORDS64, h.n_words - w_first);
+    __syncthreads();  // the previous slab has left the LDS
+    for (uint32_t i = tid; i < SLAB_WORDS64 * 2; i += SLAB_THREADS)
+      s_bits[i] = 0u;
+    if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB))
+      s_bsum[tid] = 0u;
+    if (tid == 0)
+      s_ne = 0u;
+    __syncthreads();
+    const uint32_t cell0 = SLAB * SLAB_CELLS;
+    // set the bit; true when it was set already (the point is an "extra" of its voxel)
+    auto mark = [&](uint32_t kv) -> bool {
+      const uint32_t local = kv - cell0;  // wraps to a huge value for keys below the slab and for the filler
+      if (kv == 0xffffffffu || local >= SLAB_CELLS)
+        return false;
+      const uint32_t bit = 1u << (local & 31u);
+      return (atomicOr(&s_bits[local >> 5], bit) & bit) != 0u;
+    };
+    auto stage = [&](bool extra, uint32_t kv) {
       const unsigned long long m = __ballot(extra);
       if (m)
       {
@@ -151,39 +153,59 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const
         {
           const uint32_t p = base + __popcll(m & ((1ull << lane) - 1ull));
           if (p < SLAB_EXTRA_CAP)
-            s_extra[p] = kv[u];
+            s_extra[p] = kv;
           else
-            extras[atomicAdd(&sa.counts[2 * FRAME + 1], 1u)] = kv[u];  // staging area full: straight to the list
+            extras[atomicAdd(&sa.counts[2 * FRAME + 1], 1u)] = kv;  // staging area full: straight to the list
         }
       }
-    }
-  }
-  __syncthreads();
-  // the staged extras leave with one reservation per workgroup
-  const uint32_t ne = min(s_ne, static_cast<uint32_t>(SLAB_EXTRA_CAP));
-  if (tid == 0)
-    s_gbase = ne ? atomicAdd(&sa.counts[2 * FRAME + 1], ne) : 0u;
-  // the slab: coalesced 8-byte stores + popcounts per 256-word block (phase a of the rank scan)
-  unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2) + w_first;
-  const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(s_bits);
-  for (uint32_t w = tid; w < SLAB_WORDS64; w += SLAB_THREADS)
-  {
-    const unsigned long long v = s64[w];
-    if (w < n_w)
-      bm[w] = v;
-    uint32_t c = __popcll(v);
+    };
+    constexpr int KB = 8;  // returning LDS atomics in flight per lane
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1)
-      c += __shfl_xor(c, s);
-    if (lane == 0 && c)
-      atomicAdd(&s_bsum[w / SCAN_WPB], c);
+    for (int j0 = 0; j0 < SLAB_KR; j0 += KB)
+    {
+      if (static_cast<uint32_t>(j0) * SLAB_THREADS < n_round)  // block-uniform; no break: kreg must stay in registers
+      {
+        bool ex[KB];
+#pragma unroll
+        for (int u = 0; u < KB; u++)
+          ex[u] = mark(kreg[j0 + u]);
+#pragma unroll
+        for (int u = 0; u < KB; u++)
+          stage(ex[u], kreg[j0 + u]);
+      }
+    }
+    for (uint32_t i0 = SLAB_KR * SLAB_THREADS + tid; i0 < n_round; i0 += SLAB_THREADS)  // lists beyond the register file
+    {
+      const uint32_t kv = i0 < n_keys ? keys[i0] : 0xffffffffu;
+      stage(mark(kv), kv);
+    }
+    __syncthreads();
+    // the staged extras leave with one reservation per workgroup
+    const uint32_t ne = min(s_ne, static_cast<uint32_t>(SLAB_EXTRA_CAP));
+    if (tid == 0)
+      s_gbase = ne ? atomicAdd(&sa.counts[2 * FRAME + 1], ne) : 0u;
+    // the slab: coalesced 8-byte stores + popcounts per 256-word block (phase a of the rank scan)
+    unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2) + w_first;
+    const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(s_bits);
+    for (uint32_t w = tid; w < SLAB_WORDS64; w += SLAB_THREADS)
+    {
+      const unsigned long long v = s64[w];
+      if (w < n_w)
+        bm[w] = v;
+      uint32_t c = __popcll(v);
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1)
+        c += __shfl_xor(c, s);
+      if (lane == 0 && c)
+        atomicAdd(&s_bsum[w / SCAN_WPB], c);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
+      extras[s_gbase + i] = s_extra[i];
+    const uint32_t blk0 = w_first / SCAN_WPB;
+    if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB) && static_cast<uint32_t>(tid) * SCAN_WPB < n_w)
+      blocksums[static_cast<size_t>(FRAME) * nblk_cap + blk0 + tid] = s_bsum[tid];
   }
-  __syncthreads();
-  for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
-    extras[s_gbase + i] = s_extra[i];
-  const uint32_t blk0 = w_first / SCAN_WPB;
-  if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB) && static_cast<uint32_t>(tid) * SCAN_WPB < n_w)
-    blocksums[static_cast<size_t>(FRAME) * nblk_cap + blk0 + tid] = s_bsum[tid];
 }
 
 // weights: every voxel starts at 1 (k_emit); each extra point adds 1 to its voxel

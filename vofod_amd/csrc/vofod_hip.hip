@@ -813,11 +813,13 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
     const uint32_t gk = std::max(1u, (max_pts + KEY_THREADS * KEY_PPT - 1) / (KEY_THREADS * KEY_PPT));
     KLAUNCH(h, k_key, fgrid(g, gk), dim3(KEY_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
-    KLAUNCH(h, k_slab, fgrid(g, n_slabs), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+    // workgroups per frame: all slabs in parallel for small batches, one workgroup walking them for batches that fill the chip
+    const uint32_t slab_g = n <= 32 ? n_slabs : std::max(1u, std::min(n_slabs, 512u / n));
+    KLAUNCH(h, k_slab, fgrid(g, slab_g), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
     ws.bitmap_clean = false;
     KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
     KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit);
-    KLAUNCH(h, k_count_extras, fgrid(g, 8), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
+    KLAUNCH(h, k_count_extras, fgrid(g, 24), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
     HIPCHK(hipGetLastError());
     return VOFOD_OK;
   }
