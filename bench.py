@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=32, help="independent scans per GPU per step")
+    ap.add_argument("--frames", type=int, default=256, help="independent scans per GPU per step (one workgroup per frame clusters in LDS: 256 frames fill the 256 CUs)")
     ap.add_argument("--voxel-size", type=float, default=0.25)
     ap.add_argument("--sensor", default="os1-128")
     ap.add_argument("--map-warm-scans", type=int, default=96)
@@ -245,6 +245,10 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
     alg = {
         "k_bbox": 12.0 * n_pts * F,
         "k_setbits": 12.0 * n_pts * F,
+        "k_key": 12.0 * n_pts * F,
+        "k_slab": 4.0 * V * F,             # the surviving points' keys (at least one per voxel)
+        "k_brick_ccl_lds": 16.0 * V * F,   # the whole neighbourhood + link stage of the clustering, inside LDS
+        "k_flatten<2>": 8.0 * V * F,
         "k_count": 12.0 * n_pts * F,
         "k_emit": 20.0 * V * F,
         "k_union<2>": 20.0 * V * F,
@@ -266,7 +270,7 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
             k["alg_bytes"] = alg[nm]
             k["GBps"] = alg[nm] / (k["avg_us"] * 1e-6) / 1e9
     # the voxelize+cluster path of north_star: K1-K7 (either clustering family)
-    path_prefixes = ("k_init_hdr", "k_bbox", "k_grid", "k_setbits", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten", "k_brick_")
+    path_prefixes = ("k_init_hdr", "k_bbox", "k_grid", "k_setbits", "k_key", "k_slab", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten", "k_brick_")
     path = [k for k in kernels if k.startswith(path_prefixes)]
     path_us = sum(kernels[p]["avg_us"] for p in path)
     dom = max(path, key=lambda p: kernels[p]["avg_us"])
