@@ -31,6 +31,10 @@ constexpr int LB_LANES = 8;           // lanes sharing one brick in phase D
 constexpr int LB_MAX_ROWS = 16;       // (dy,dz) rows of the half stencil (13 for a reach of 2 bricks)
 constexpr int LB_MAX_OFF = 64;
 constexpr int LB_WIN = 7;             // widest x-window: reach of 3 bricks
+#ifndef VOFOD_LB_ST_ROWS
+#define VOFOD_LB_ST_ROWS 384
+#endif
+constexpr int LB_ST_ROWS = VOFOD_LB_ST_ROWS;  // components per frame whose statistics are gathered in LDS (36 B each); the rest use global atomics
 constexpr int32_t CCL_RETRY_STATUS = 1000;  // internal FrameHdr::status, never returned through the C-ABI
 
 struct LbRow
@@ -190,7 +194,9 @@ __device__ __forceinline__ uint32_t lb_node(const uint32_t* bits, const uint16_t
 
 __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, VoxelArrays va_all,
                                                              uint32_t* __restrict__ labels_all, const unsigned long long* __restrict__ bitmaps,
-                                                             const uint32_t* __restrict__ wprefix_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, unsigned long long* __restrict__ prof)
+                                                             const uint32_t* __restrict__ wprefix_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, const MapGeom mg, const unsigned long long* __restrict__ mapclose,
+                                                             const unsigned long long* __restrict__ mapbits, const CloseRow* __restrict__ crows, int n_crows,
+                                                             unsigned long long* __restrict__ prof)
 {
   __shared__ uint32_t s_bits[LB_BITWORDS + 2];      // brick-lattice bitmap
   __shared__ uint16_t s_pre[LB_BITWORDS];           // exclusive popcount prefix per word = node index of the word's first brick
@@ -543,12 +549,14 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
   const unsigned long long* bm = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   const uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   uint32_t my_root[LB_MAX / LB_THREADS], my_min[LB_MAX / LB_THREADS];
+  unsigned long long my_w[LB_MAX / LB_THREADS];
 #pragma unroll
   for (int r = 0; r < LB_MAX / LB_THREADS; r++)
   {
     const uint32_t i = r * LB_THREADS + tid;
     my_root[r] = 0xffffffffu;
     my_min[r] = 0xffffffffu;
+    my_w[r] = 0ull;
     if (i < n)
     {
       uint32_t root = i, p;
@@ -557,7 +565,8 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
       my_root[r] = root;
       const uint32_t xyz = s_xyz[i];
       const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
-      const int bit = __ffsll(static_cast<long long>(s_word[i])) - 1;
+      my_w[r] = s_word[i];
+      const int bit = __ffsll(static_cast<long long>(my_w[r])) - 1;
       const uint32_t key = static_cast<uint32_t>(((4 * bz + (bit >> 4)) * h.div_b[1] + (4 * by + ((bit >> 2) & 3))) * h.div_b[0] + 4 * bx + (bit & 3));
       my_min[r] = rank_of(bm, wprefix, key);
     }
@@ -579,18 +588,157 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
     if (my_root[r] != 0xffffffffu)
       atomicMin(&s_cmin[my_root[r]], my_min[r]);
   __syncthreads();
-  // the roots' statistics slots (size, lattice box, close flag): k_emit left them to this kernel (lean emission)
+  // ---- cluster statistics (size, lattice box, close flag) gathered brick by brick: what k_flatten does voxel by voxel for
+  // the other clustering paths.  The whole frame is in this workgroup: every component gets an index and a row in an LDS
+  // table (upper half of s_word, free by now); components beyond the table go through global atomics on their slots.
+  uint16_t* s_cidx = reinterpret_cast<uint16_t*>(s_word + LB_MAX / 2);               // node (root) -> component index
+  uint32_t* st_label = reinterpret_cast<uint32_t*>(s_cidx + LB_MAX);                 // LB_ST_ROWS x {label, count, close, box[6]}
+  uint32_t* st_cnt = st_label + LB_ST_ROWS;
+  uint32_t* st_close = st_cnt + LB_ST_ROWS;
+  int* st_box = reinterpret_cast<int*>(st_close + LB_ST_ROWS);
+  if (tid == 0)
+    s_nh = 0;  // reused: number of components
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < LB_MAX / LB_THREADS; r++)
-    if (my_root[r] == static_cast<uint32_t>(r * LB_THREADS + tid))
+  {
+    const bool is_root = my_root[r] == static_cast<uint32_t>(r * LB_THREADS + tid);
+    const unsigned long long m = __ballot(is_root);
+    if (!m)
+      continue;
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&s_nh, static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, leader);
+    if (is_root)
+    {
+      const uint32_t c = base + __popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t label = s_cmin[my_root[r]];
+      s_cidx[my_root[r]] = static_cast<uint16_t>(min(c, static_cast<uint32_t>(LB_ST_ROWS)));
+      if (c < LB_ST_ROWS)
+      {
+        st_label[c] = label;
+        st_cnt[c] = 0;
+        st_close[c] = 0;
+        for (int a = 0; a < 3; a++)
+        {
+          st_box[6 * c + a] = 0x7fffffff;
+          st_box[6 * c + 3 + a] = static_cast<int>(0x80000000u);
+        }
+      }
+      else
+      {
+        // components beyond the table accumulate in their global slots (k_emit left those to this kernel: lean emission);
+        // initialised with atomics, which are ordered at L2 with the accumulating atomics of the other lanes
+        atomicExch(&va.csize[label], 0u);
+        atomicExch(&va.cclose[label], 0u);
+        for (int a = 0; a < 3; a++)
+        {
+          atomicExch(&va.cbox[6 * label + a], 0x7fffffff);
+          atomicExch(&va.cbox[6 * label + 3 + a], static_cast<int>(0x80000000u));
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LB_MAX / LB_THREADS; r++)
+  {
+    const uint32_t i = r * LB_THREADS + tid;
+    if (i >= n)
+      continue;
+    const unsigned long long W = my_w[r];
+    const uint32_t c = s_cidx[my_root[r]];
+    const uint32_t xyz = s_xyz[i];
+    const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
+    // extents of the set bits along x, y, z (bit p = x + 4y + 16z)
+    unsigned long long t = W | (W >> 16) | (W >> 32) | (W >> 48);
+    uint32_t ox = static_cast<uint32_t>(t) & 0xffffu;
+    ox = (ox | (ox >> 4) | (ox >> 8) | (ox >> 12)) & 0xfu;
+    t = W | (W >> 1);
+    t |= t >> 2;  // bit 4y + 16z: row (y,z) is occupied
+    unsigned long long ty = t | (t >> 16) | (t >> 32) | (t >> 48);
+    const uint32_t oy = (static_cast<uint32_t>(ty) & 1u) | ((static_cast<uint32_t>(ty) >> 3) & 2u) | ((static_cast<uint32_t>(ty) >> 6) & 4u) | ((static_cast<uint32_t>(ty) >> 9) & 8u);
+    const uint32_t oz = ((W & 0xffffull) ? 1u : 0u) | ((W & 0xffff0000ull) ? 2u : 0u) | ((W & 0xffff00000000ull) ? 4u : 0u) | ((W >> 48) ? 8u : 0u);
+    const int lo[3] = {4 * bx + __ffs(static_cast<int>(ox)) - 1, 4 * by + __ffs(static_cast<int>(oy)) - 1, 4 * bz + __ffs(static_cast<int>(oz)) - 1};
+    const int hi[3] = {4 * bx + 31 - __clz(static_cast<int>(ox)), 4 * by + 31 - __clz(static_cast<int>(oy)), 4 * bz + 31 - __clz(static_cast<int>(oz))};
+    const uint32_t cnt = __popcll(W);
+    // hasCloseTo through the dilated map image, until the component is known to be close
+    bool hit = false;
+    if (mapclose && !(c < LB_ST_ROWS ? st_close[c] : 0u))
+    {
+      unsigned long long a = W;
+      while (a && !hit)
+      {
+        // eight voxels per round: their image words are fetched together, not one dependent load after the other
+        constexpr int CB = 8;
+        uint64_t Lq[CB];
+        unsigned long long wq[CB];
+#pragma unroll
+        for (int q = 0; q < CB; q++)
+        {
+          Lq[q] = ~0ull;
+          if (!a)
+            continue;
+          const int p = __ffsll(static_cast<long long>(a)) - 1;
+          a &= a - 1;
+          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+          const int mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
+          const int my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
+          const int mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
+          if (mx_ >= 0 && mx_ < mg.sx && my_ >= 0 && my_ < mg.sy && mz_ >= 0 && mz_ < mg.sz)
+            Lq[q] = (static_cast<uint64_t>(mz_) * mg.sy + my_) * mg.sx + mx_;
+          else  // a centre outside the map (a point on the far face of the operation area): the clipped stencil sweep
+            for (int rr = 0; rr < n_crows && !hit; rr++)
+              hit = close_row_hit(mg, mapbits, crows[rr], mx_, my_, mz_);
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++)
+          wq[q] = Lq[q] != ~0ull ? mapclose[Lq[q] >> 6] : 0ull;
+#pragma unroll
+        for (int q = 0; q < CB; q++)
+          hit |= Lq[q] != ~0ull && ((wq[q] >> (Lq[q] & 63)) & 1ull);
+      }
+    }
+    if (c < LB_ST_ROWS)
+    {
+      atomicAdd(&st_cnt[c], cnt);
+      if (hit)
+        st_close[c] = 1u;
+      for (int a = 0; a < 3; a++)
+      {
+        atomicMin(&st_box[6 * c + a], lo[a]);
+        atomicMax(&st_box[6 * c + 3 + a], hi[a]);
+      }
+    }
+    else
     {
       const uint32_t label = s_cmin[my_root[r]];
-      va.csize[label] = 0;
-      va.cclose[label] = 0;
-      int* cb = &va.cbox[6 * label];
-      cb[0] = cb[1] = cb[2] = 0x7fffffff;
-      cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+      atomicAdd(&va.csize[label], cnt);
+      if (hit)
+        atomicOr(&va.cclose[label], 1u);
+      for (int a = 0; a < 3; a++)
+      {
+        atomicMin(&va.cbox[6 * label + a], lo[a]);
+        atomicMax(&va.cbox[6 * label + 3 + a], hi[a]);
+      }
     }
+  }
+  __syncthreads();
+  {
+    const uint32_t nc = min(s_nh, static_cast<uint32_t>(LB_ST_ROWS));
+    for (uint32_t c = tid; c < nc; c += LB_THREADS)
+    {
+      const uint32_t label = st_label[c];
+      va.csize[label] = st_cnt[c];
+      va.cclose[label] = st_close[c];
+      for (int a = 0; a < 6; a++)
+        va.cbox[6 * label + a] = st_box[6 * c + a];
+    }
+  }
   LB_STAMP(5);
   for (uint32_t v0 = tid; v0 < V; v0 += LB_THREADS * VU)
   {

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const Gr
 }
 
 // ---- exclusive prefix sum of the bitmap's word popcounts (3 phases) ------------------------
-constexpr int SCAN_WPT = 1;                    // words per thread
+constexpr int SCAN_WPT = 4;                    // words per thread
 constexpr int SCAN_WPB = 256 * SCAN_WPT;       // words per block
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)

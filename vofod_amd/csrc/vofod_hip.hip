@@ -181,6 +181,7 @@ struct Workspace
   std::vector<FrameArgs> h_args;
   bool bricks_preset = false;  // k_emit already registered the voxels in their bricks (fused brick_set)
   std::vector<vofod_scan> job_scans;  // the submitted batch (re-run when the LDS clustering kernel overflows)
+  bool slab_bitmap = false;     // the current bitmaps were written by k_slab (dense, zeros included)
   bool lean_emit = false;       // k_emit skipped the per-root slots: launch_cluster must run the LDS clustering kernel
   bool closefar_fused = false;  // launch_cluster answered hasCloseTo as well (dilated image inside k_flatten)
   bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
@@ -792,6 +793,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   g.xcd_map = (n >= 8 && xcd_on) ? 1u : 0u;
   // lean emission: the LDS clustering kernel will follow and initialises the per-root slots itself (see plan_lds_ccl)
   ws.lean_emit = lean_hint && !bricks && !g.xcd_map && !two_phase;
+  ws.slab_bitmap = false;
   const uint32_t lean_bit = ws.lean_emit ? 0x80000000u : 0u;
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
@@ -808,7 +810,8 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   const uint32_t n_slabs = (ws.words_cap + SLAB_WORDS64 - 1) / SLAB_WORDS64;
   if (slabs_on && !want_ptrank && !bricks && n_slabs <= SLAB_MAX && !g.xcd_map)
   {
-    if (!ws.bitmap_clean)  // words beyond this batch's lattices must read as zero (neighbour windows run into the padding)
+    ws.slab_bitmap = true;
+    if (!ws.bitmap_clean && !g.sparse_prefix)  // voxel-level clustering: neighbour windows run into the words past the lattice, they must read as zero
       HIPCHK(hipMemsetAsync(ws.d_bitmaps, 0, sizeof(unsigned long long) * ws.F * (static_cast<size_t>(ws.words_cap) + 2), h->stream));
     HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
     const uint32_t gk = std::max(1u, (max_pts + KEY_THREADS * KEY_PPT - 1) / (KEY_THREADS * KEY_PPT));
@@ -972,7 +975,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       static unsigned long long* d_prof = nullptr;
       if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 16 * 4096));
-      KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), d_prof);
+      KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table),
+              h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, d_prof);
       if (d_prof)
       {
         // VOFOD_LDS_PROF=1 (diagnostics): phase durations of frame 0 from the 100 MHz wall clock
@@ -982,8 +986,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
         std::fprintf(stderr, "[k_brick_ccl_lds] n %llu hits %llu open %llu | A %.1f B %.1f C %.1f Da %.1f Db %.1f Dc %.1f E %.1f label %.1f us\n", t[11], t[9], t[10], (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[7] - t[3]) * 0.01, (t[8] - t[7]) * 0.01, (t[4] - t[8]) * 0.01,
                      (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01);
       }
-      KLAUNCH(h, k_flatten<2>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap, h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows);
-      ws.closefar_fused = mapclose != nullptr;  // hasCloseTo answered inside the flatten kernel
+      ws.closefar_fused = mapclose != nullptr;  // the kernel gathered the cluster statistics and answered hasCloseTo as well
       HIPCHK(hipGetLastError());
       return VOFOD_OK;
     }
@@ -1371,8 +1374,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   up.min_points = dp.classification__min_points;
   up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
   up.no_update = no_update;
-  KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, ws.d_bitmaps);
-  ws.bitmap_clean = true;
+  // k_slab rewrites the bitmap densely and the brick clustering reads it at set bits only: no need to clean it after use
+  const bool keep_dirty = ws.slab_bitmap && g.sparse_prefix;
+  KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, keep_dirty ? nullptr : ws.d_bitmaps);
+  ws.bitmap_clean = !keep_dirty;
   KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
   HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
   if (dbg)
