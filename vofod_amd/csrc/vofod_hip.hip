@@ -808,7 +808,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   static const bool slabs_on = !(std::getenv("VOFOD_SLABS") && std::atoi(std::getenv("VOFOD_SLABS")) == 0);
   constexpr uint32_t SLAB_MAX = 32;
   const uint32_t n_slabs = (ws.words_cap + SLAB_WORDS64 - 1) / SLAB_WORDS64;
-  if (slabs_on && !want_ptrank && !bricks && n_slabs <= SLAB_MAX && !g.xcd_map)
+  if (slabs_on && n >= 4 && !want_ptrank && !bricks && n_slabs <= SLAB_MAX && !g.xcd_map)  // a single frame is served faster by the whole chip through the global bitmap
   {
     ws.slab_bitmap = true;
     if (!ws.bitmap_clean && !g.sparse_prefix)  // voxel-level clustering: neighbour windows run into the words past the lattice, they must read as zero
