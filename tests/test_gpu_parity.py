@@ -239,6 +239,24 @@ def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, 
         np.testing.assert_array_equal(g1[1], w1[1])
 
 
+def test_large_batch_takes_the_fused_slab_emission(oracle, hip):
+    """>= 128 frames per batch: k_slab_emit (bitmap slab in LDS -> voxel records) replaces k_slab + k_scan_b + k_emit"""
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.25, max_batch=136)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    scene = synth.make_scene(43, n_targets=2)
+    base = synth.scan_sequence(scene, "os1-16", 17, seed0=900)
+    scans = [base[i % 17] for i in range(136)]
+    tfs = np.stack([s.tf for s in scans])
+    da, pa, ga = ref.process_batch([s.scan for s in scans], tfs, debug=True)
+    db, pb, gb = dev.process_batch([s.scan for s in scans], tfs, debug=True)
+    np.testing.assert_array_equal(pb, pa)
+    assert_detections_equal(da, db)
+    for x, y in zip(ga, gb):
+        assert_scan_debug_equal(x, y)
+    assert sum(len(x["weighted"]) for x in ga) > 136 * 1000
+
+
 def test_error_paths(oracle, hip):
     ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
     scene = synth.make_scene(1)

@@ -536,7 +536,13 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   } while (0)
   CREATE_CHK(hipSetDevice(h->device));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CREATE_CHK(hipStreamCreateWithFlags(&h->stream_tail, hipStreamNonBlocking));
+  {
+    // the tail's one small kernel (k_explore) has the host waiting for it: highest priority, so that it is dispatched at the
+    // next kernel boundary of the batches in flight instead of behind their queued kernels
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_tail, hipStreamNonBlocking, prio_hi));
+  }
   h->chain_stream[0] = h->stream;
   for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
     CREATE_CHK(hipStreamCreateWithFlags(&h->chain_stream[t], hipStreamNonBlocking));

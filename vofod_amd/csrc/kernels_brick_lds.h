@@ -196,6 +196,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
                                                              uint32_t* __restrict__ labels_all, const unsigned long long* __restrict__ bitmaps,
                                                              const uint32_t* __restrict__ wprefix_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, const MapGeom mg, const unsigned long long* __restrict__ mapclose,
                                                              const unsigned long long* __restrict__ mapbits, const CloseRow* __restrict__ crows, int n_crows,
+                                                             const UpdateParams up, ClusterRec* __restrict__ table_all, CandMember* __restrict__ cand_all, int write_tables,
                                                              unsigned long long* __restrict__ prof)
 {
   __shared__ uint32_t s_bits[LB_BITWORDS + 2];      // brick-lattice bitmap
@@ -728,6 +729,17 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
     }
   }
   __syncthreads();
+  // the rows leave for the global slots; with write_tables (read-only batches) this kernel also does k_finalize's part:
+  // one cluster record per component and, below, the member list of the candidate (far, small enough) clusters
+  uint8_t* st_cand = reinterpret_cast<uint8_t*>(st_box + 6 * LB_ST_ROWS);
+  ClusterRec* table = table_all + static_cast<size_t>(FRAME) * g.vox_cap;  // (the hit list that lived here is dead)
+  CandMember* cands = cand_all + static_cast<size_t>(FRAME) * g.vox_cap;
+  auto is_cand = [&](uint32_t close, uint32_t size, const int* box) {
+    int ext_ok = 1;
+    for (int a = 0; a < 3; a++)
+      ext_ok &= (static_cast<float>(box[3 + a] - box[a]) * g.leaf[a] <= up.cand_max_extent);
+    return !close && static_cast<int>(size) >= up.min_points && ext_ok;
+  };
   {
     const uint32_t nc = min(s_nh, static_cast<uint32_t>(LB_ST_ROWS));
     for (uint32_t c = tid; c < nc; c += LB_THREADS)
@@ -737,10 +749,27 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
       va.cclose[label] = st_close[c];
       for (int a = 0; a < 6; a++)
         va.cbox[6 * label + a] = st_box[6 * c + a];
+      if (write_tables)
+      {
+        const bool cand = is_cand(st_close[c], st_cnt[c], &st_box[6 * c]);
+        st_cand[c] = cand ? 1 : 0;
+        ClusterRec rec;
+        rec.root = label;
+        rec.size = st_cnt[c];
+        for (int a = 0; a < 3; a++)
+        {
+          rec.imin[a] = st_box[6 * c + a];
+          rec.imax[a] = st_box[6 * c + 3 + a];
+        }
+        rec.close = st_close[c];
+        rec.cand = cand ? 1u : 0u;
+        table[atomicAdd(&h.C, 1u)] = rec;
+      }
     }
   }
+  __syncthreads();
   LB_STAMP(5);
-  for (uint32_t v0 = tid; v0 < V; v0 += LB_THREADS * VU)
+  for (uint32_t v0 = tid; v0 < Vround; v0 += LB_THREADS * VU)
   {
     uint32_t bbv[VU];
 #pragma unroll
@@ -753,8 +782,65 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
     for (int u = 0; u < VU; u++)
     {
       const uint32_t v = v0 + u * LB_THREADS;
+      if (v0 + u * LB_THREADS - tid >= Vround)  // block-uniform
+        break;
+      bool cand = false;
+      uint32_t label = 0;
       if (v < V)
-        labels[v] = s_cmin[s_par[lb_node(s_bits, s_pre, bbv[u] >> 6)]];
+      {
+        const uint32_t root = s_par[lb_node(s_bits, s_pre, bbv[u] >> 6)];
+        label = s_cmin[root];
+        labels[v] = label;
+        if (write_tables)
+        {
+          const uint32_t c = s_cidx[root];
+          if (c < LB_ST_ROWS)
+            cand = st_cand[c] != 0;
+          else
+          {
+            // a component beyond the LDS table: its statistics sit in the global slots (written with atomics above)
+            int box[6];
+            for (int a = 0; a < 6; a++)
+              box[a] = __hip_atomic_load(&va.cbox[6 * label + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t close = __hip_atomic_load(&va.cclose[label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t size = __hip_atomic_load(&va.csize[label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cand = is_cand(close, size, box);
+            if (v == label)  // the component's first voxel writes its record
+            {
+              ClusterRec rec;
+              rec.root = label;
+              rec.size = size;
+              for (int a = 0; a < 3; a++)
+              {
+                rec.imin[a] = box[a];
+                rec.imax[a] = box[3 + a];
+              }
+              rec.close = close;
+              rec.cand = cand ? 1u : 0u;
+              table[atomicAdd(&h.C, 1u)] = rec;
+            }
+          }
+        }
+      }
+      if (write_tables)
+      {
+        const unsigned long long m = __ballot(cand);
+        if (m)
+        {
+          const int leader = __ffsll(static_cast<long long>(m)) - 1;
+          uint32_t base = 0;
+          if (lane == leader)
+            base = atomicAdd(&h.n_cand, static_cast<uint32_t>(__popcll(m)));
+          base = __shfl(base, leader);
+          if (cand)
+          {
+            CandMember cm;
+            cm.root = label;
+            cm.v = v;
+            cands[base + __popcll(m & ((1ull << lane) - 1ull))] = cm;
+          }
+        }
+      }
     }
   }
   LB_STAMP(6);

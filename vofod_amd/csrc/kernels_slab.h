@@ -208,6 +208,238 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const
   }
 }
 
+// ---- large batches: slab voxelisation and emission in one kernel --------------------------------------------
+// With one workgroup per frame walking the slabs in order, the running voxel count is known inside the workgroup: the
+// voxel records can leave straight from the LDS slab, in key order, and k_scan_b / k_emit (a second trip of the bitmap
+// through global memory, 250 us per 256 frames) disappear.  Per slab: the 64-word groups of the bitmap are dealt
+// round-robin to the 16 waves; pass 1 counts the groups, one wave scans the 256 group totals, pass 2 writes bitmap and
+// rank prefix (coalesced) and emits the group's voxels 64 at a time: slot s finds its word by a binary search over the
+// wave's inclusive popcounts (register shuffles), picks its bit by popcount descent, and the lanes store consecutive ranks.
+constexpr int SE_EXTRA_CAP = 4096;
+constexpr int SE_GROUPS = SLAB_WORDS64 / 64;  // 256 groups of 64 words per slab
+
+__device__ __forceinline__ int select_bit64(unsigned long long w, uint32_t u)
+{
+  // position of the u-th (0-based) set bit of w, by popcount descent
+  int pos = 0;
+#pragma unroll
+  for (int width = 32; width >= 1; width >>= 1)
+  {
+    const unsigned long long lowmask = (width == 32) ? 0xffffffffull : ((1ull << width) - 1ull);
+    const uint32_t c = __popcll((w >> pos) & lowmask);
+    if (u >= c)
+    {
+      u -= c;
+      pos += width;
+    }
+  }
+  return pos;
+}
+
+__global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, unsigned long long* __restrict__ bitmaps,
+                                                           uint32_t* __restrict__ wprefix_all, VoxelArrays va_all, uint32_t init_count)
+{
+  __shared__ uint32_t s_bits[SLAB_WORDS64 * 2];
+  __shared__ uint32_t s_extra[SE_EXTRA_CAP];
+  __shared__ uint32_t s_gsum[SE_GROUPS];  // per group: voxel count, then exclusive base
+  __shared__ uint32_t s_ne, s_gbase, s_total;
+  const uint32_t FRAME = blockIdx.x;
+  FrameHdr& h = hdrs[FRAME];
+  const uint32_t n_slabs = (h.n_words + SLAB_WORDS64 - 1) / SLAB_WORDS64;
+  if (n_slabs == 0)
+    return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n_keys = sa.counts[2 * FRAME];
+  const uint32_t* keys = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
+  uint32_t* extras = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
+  unsigned long long* bm_frame = bitmaps + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const uint32_t n_round = (n_keys + 63u) & ~63u;
+  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+  const uint32_t nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
+  uint32_t kreg[SLAB_KR];
+#pragma unroll
+  for (int j = 0; j < SLAB_KR; j++)
+  {
+    const uint32_t i = j * SLAB_THREADS + tid;
+    kreg[j] = i < n_keys ? keys[i] : 0xffffffffu;
+  }
+  uint32_t run_base = 0;
+  for (uint32_t SLAB = 0; SLAB < n_slabs; SLAB++)
+  {
+    const uint32_t w_first = SLAB * SLAB_WORDS64;
+    const uint32_t n_w = min(SLAB_WORDS64, h.n_words - w_first);
+    __syncthreads();  // the previous slab has left the LDS
+    for (uint32_t i = tid; i < SLAB_WORDS64 * 2; i += SLAB_THREADS)
+      s_bits[i] = 0u;
+    if (tid == 0)
+      s_ne = 0u;
+    __syncthreads();
+    const uint32_t cell0 = SLAB * SLAB_CELLS;
+    auto mark = [&](uint32_t kv) -> bool {
+      const uint32_t local = kv - cell0;
+      if (kv == 0xffffffffu || local >= SLAB_CELLS)
+        return false;
+      const uint32_t bit = 1u << (local & 31u);
+      return (atomicOr(&s_bits[local >> 5], bit) & bit) != 0u;
+    };
+    auto stage = [&](bool extra, uint32_t kv) {
+      const unsigned long long m = __ballot(extra);
+      if (m)
+      {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&s_ne, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader);
+        if (extra)
+        {
+          const uint32_t p = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (p < SE_EXTRA_CAP)
+            s_extra[p] = kv;
+          else
+            extras[atomicAdd(&sa.counts[2 * FRAME + 1], 1u)] = kv;
+        }
+      }
+    };
+    constexpr int KB = 8;
+#pragma unroll
+    for (int j0 = 0; j0 < SLAB_KR; j0 += KB)
+    {
+      if (static_cast<uint32_t>(j0) * SLAB_THREADS < n_round)
+      {
+        bool ex[KB];
+#pragma unroll
+        for (int u = 0; u < KB; u++)
+          ex[u] = mark(kreg[j0 + u]);
+#pragma unroll
+        for (int u = 0; u < KB; u++)
+          stage(ex[u], kreg[j0 + u]);
+      }
+    }
+    for (uint32_t i0 = SLAB_KR * SLAB_THREADS + tid; i0 < n_round; i0 += SLAB_THREADS)
+    {
+      const uint32_t kv = i0 < n_keys ? keys[i0] : 0xffffffffu;
+      stage(mark(kv), kv);
+    }
+    __syncthreads();
+    const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(s_bits);
+    // pass 1: voxel count of every group (group gi belongs to wave gi % 16)
+    for (int gi = wave; gi < SE_GROUPS; gi += SLAB_THREADS / 64)
+    {
+      uint32_t c = __popcll(s64[gi * 64 + lane]);
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1)
+        c += __shfl_xor(c, sft);
+      if (lane == 0)
+        s_gsum[gi] = c;
+    }
+    __syncthreads();
+    if (wave == 0)
+    {
+      // exclusive scan of the 256 group totals: 4 per lane
+      uint32_t v4[4], tot = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        v4[q] = s_gsum[lane * 4 + q];
+        tot += v4[q];
+      }
+      const uint32_t incl = wave_incl_scan(tot);
+      uint32_t run = incl - tot;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        s_gsum[lane * 4 + q] = run;
+        run += v4[q];
+      }
+      if (lane == 63)
+        s_total = incl;
+    }
+    const uint32_t ne = min(s_ne, static_cast<uint32_t>(SE_EXTRA_CAP));
+    if (tid == 64)
+      s_gbase = ne ? atomicAdd(&sa.counts[2 * FRAME + 1], ne) : 0u;
+    __syncthreads();
+    const uint32_t slab_total = s_total;
+    if (run_base + slab_total > g.vox_cap)
+    {
+      if (tid == 0)
+      {
+        h.status = VOFOD_ERR_CAPACITY;  // as k_scan_b
+        h.V = 0;
+      }
+      return;
+    }
+    for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
+      extras[s_gbase + i] = s_extra[i];
+    // pass 2: bitmap + rank prefix out, voxel records out
+    for (int gi = wave; gi < SE_GROUPS; gi += SLAB_THREADS / 64)
+    {
+      const uint32_t w = gi * 64 + lane;
+      const unsigned long long word = s64[w];
+      const uint32_t c = __popcll(word);
+      const uint32_t incl = wave_incl_scan(c);
+      const uint32_t T = __shfl(incl, 63);
+      const uint32_t gbase = run_base + s_gsum[gi];
+      if (w < n_w)
+      {
+        bm_frame[w_first + w] = word;
+        wprefix[w_first + w] = gbase + incl - c;
+      }
+      for (uint32_t s0 = 0; s0 < T; s0 += 64)
+      {
+        const uint32_t sidx = s0 + lane;
+        // owner lane: the first lane whose inclusive count exceeds the slot index
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int step = 0; step < 6; step++)
+        {
+          const int mid = (lo + hi) >> 1;
+          const uint32_t v = __shfl(incl, mid);
+          if (v <= sidx)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        const int owner = lo;
+        const uint32_t oincl = __shfl(incl, owner), oc = __shfl(c, owner);
+        const unsigned long long oword = __shfl(word, owner);
+        if (sidx < T)
+        {
+          const int bit = select_bit64(oword, sidx - (oincl - oc));
+          const uint32_t key = (w_first + gi * 64 + owner) * 64u + bit;
+          const uint32_t rank = gbase + sidx;
+          const int k2 = key / dxy;
+          const int rem = key - k2 * dxy;
+          const int k1 = rem / dx;
+          const int k0 = rem - k1 * dx;
+          float4 p;
+          p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
+          p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
+          p.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+          p.w = __uint_as_float(init_count & 0x7fffffffu);
+          va.pts[rank] = p;
+          va.key[rank] = key;
+          va.bb[rank] = (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
+          if (!(init_count & 0x80000000u))
+          {
+            va.parent[rank] = rank;
+            va.csize[rank] = 0;
+            va.cclose[rank] = 0;
+            int* cb = &va.cbox[6 * rank];
+            cb[0] = cb[1] = cb[2] = 0x7fffffff;
+            cb[3] = cb[4] = cb[5] = static_cast<int>(0x80000000u);
+          }
+        }
+      }
+    }
+    run_base += slab_total;
+  }
+  if (tid == 0)
+    h.V = run_base;
+}
+
 // weights: every voxel starts at 1 (k_emit); each extra point adds 1 to its voxel
 __global__ __launch_bounds__(256) void k_count_extras(const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, const unsigned long long* __restrict__ bitmaps,
                                                       const uint32_t* __restrict__ wprefix_all, VoxelArrays va_all)

@@ -183,6 +183,7 @@ struct Workspace
   std::vector<vofod_scan> job_scans;  // the submitted batch (re-run when the LDS clustering kernel overflows)
   bool slab_bitmap = false;     // the current bitmaps were written by k_slab (dense, zeros included)
   bool lean_emit = false;       // k_emit skipped the per-root slots: launch_cluster must run the LDS clustering kernel
+  bool finalize_fused = false;  // ... and the cluster table / candidate list too
   bool closefar_fused = false;  // launch_cluster answered hasCloseTo as well (dilated image inside k_flatten)
   bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
   // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
@@ -816,12 +817,22 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
     const uint32_t gk = std::max(1u, (max_pts + KEY_THREADS * KEY_PPT - 1) / (KEY_THREADS * KEY_PPT));
     KLAUNCH(h, k_key, fgrid(g, gk), dim3(KEY_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
-    // workgroups per frame: all slabs in parallel for small batches, one workgroup walking them for batches that fill the chip
-    const uint32_t slab_g = n <= 32 ? n_slabs : std::max(1u, std::min(n_slabs, 512u / n));
-    KLAUNCH(h, k_slab, fgrid(g, slab_g), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+    // VOFOD_SLAB_EMIT=0 keeps the separate emission kernels for every batch size
+    static const bool slab_emit_on = !(std::getenv("VOFOD_SLAB_EMIT") && std::atoi(std::getenv("VOFOD_SLAB_EMIT")) == 0);
     ws.bitmap_clean = false;
-    KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-    KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit);
+    if (slab_emit_on && n >= 128)
+    {
+      // batches that fill the chip: one workgroup per frame walks the slabs in order and emits the voxel records itself
+      KLAUNCH(h, k_slab_emit, dim3(n), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va, 1u | lean_bit);
+    }
+    else
+    {
+      // workgroups per frame: all slabs in parallel for small batches, fewer workgroups walking several slabs otherwise
+      const uint32_t slab_g = n <= 32 ? n_slabs : std::max(1u, std::min(n_slabs, 512u / n));
+      KLAUNCH(h, k_slab, fgrid(g, slab_g), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
+      KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
+      KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit);
+    }
     KLAUNCH(h, k_count_extras, fgrid(g, 24), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
     HIPCHK(hipGetLastError());
     return VOFOD_OK;
@@ -953,8 +964,10 @@ bool plan_lds_ccl(const vofod_handle* h, const vofod_handle::ClusterTables* ct, 
 }
 
 // K7: Euclidean clustering of the frames in `ws`
-int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax, bool allow_lds = false, const unsigned long long* mapclose = nullptr)
+int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax, bool allow_lds = false, const unsigned long long* mapclose = nullptr,
+                   const UpdateParams* up_tables = nullptr)
 {
+  ws.finalize_fused = false;
   ws.closefar_fused = false;
   vofod_handle::ClusterTables* ct = nullptr;
   const int rt = cluster_tables(h, g, tol, cmax, &ct);
@@ -976,7 +989,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 16 * 4096));
       KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table),
-              h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, d_prof);
+              h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof);
+      ws.finalize_fused = up_tables && mapclose;  // cluster table + candidate members written as well (k_finalize's part for read-only batches)
       if (d_prof)
       {
         // VOFOD_LDS_PROF=1 (diagnostics): phase durations of frame 0 from the 100 MHz wall clock
@@ -1353,7 +1367,17 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     HIPCHK(hipEventRecord(ev[1], h->stream));
 
   // ---- K7 clusterCloud :932
-  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr);
+  UpdateParams up{};
+  up.score_point = static_cast<float>(dp.voxel_map__scores__point);
+  up.score_unknown = static_cast<float>(dp.voxel_map__scores__unknown);
+  up.min_points = dp.classification__min_points;
+  up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
+  up.no_update = no_update;
+  // k_slab rewrites the bitmap densely and the brick clustering reads it at set bits only: no need to clean it after use;
+  // then the LDS clustering kernel can write the cluster table and the candidate list itself (nothing left for k_finalize)
+  const bool keep_dirty = ws.slab_bitmap && g.sparse_prefix;
+  r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr,
+                     (keep_dirty && no_update) ? &up : nullptr);
   if (r != VOFOD_OK)
     return r;
   if (dbg)
@@ -1368,16 +1392,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     HIPCHK(hipEventRecord(ev[3], h->stream));
 
   // ---- K10 updateVMaps :943-950 + cluster table + candidate members
-  UpdateParams up{};
-  up.score_point = static_cast<float>(dp.voxel_map__scores__point);
-  up.score_unknown = static_cast<float>(dp.voxel_map__scores__unknown);
-  up.min_points = dp.classification__min_points;
-  up.cand_max_extent = static_cast<float>(dp.classification__max_size * (1.0 + 1e-4) + 1e-3 * sp.voxel_size);
-  up.no_update = no_update;
-  // k_slab rewrites the bitmap densely and the brick clustering reads it at set bits only: no need to clean it after use
-  const bool keep_dirty = ws.slab_bitmap && g.sparse_prefix;
-  KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, keep_dirty ? nullptr : ws.d_bitmaps);
+  if (!ws.finalize_fused)
+    KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, keep_dirty ? nullptr : ws.d_bitmaps);
   ws.bitmap_clean = !keep_dirty;
+  ws.finalize_fused = false;
   KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
   HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
   if (dbg)
