@@ -434,7 +434,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
   }
   if (prof && tid == 0)
     prof[static_cast<size_t>(FRAME) * 16 + 7] = wall_clock64();
-  constexpr int HU = 4;
+  constexpr int HU = 8;
   for (uint32_t i0 = tid; i0 < nh; i0 += LB_THREADS * HU)
   {
     uint32_t hv[HU];

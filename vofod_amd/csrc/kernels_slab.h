@@ -96,7 +96,7 @@ constexpr int SLAB_KR = 48;  // keys a lane keeps in registers across the slabs 
 __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, unsigned long long* __restrict__ bitmaps,
                                                       uint32_t* __restrict__ blocksums, uint32_t nblk_cap)
 {
-  __shared__ uint32_t s_bits[SLAB_WORDS64 * 2];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[SLAB_WORDS64 * 2];
   __shared__ uint32_t s_extra[SLAB_EXTRA_CAP];
   __shared__ uint32_t s_bsum[SLAB_WORDS64 / SCAN_WPB];
   __shared__ uint32_t s_ne, s_gbase;
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const
     const uint32_t w_first = SLAB * SLAB_WORDS64;
     const uint32_t n_w = min(SLAB_WORDS64, h.n_words - w_first);
     __syncthreads();  // the previous slab has left the LDS
-    for (uint32_t i = tid; i < SLAB_WORDS64 * 2; i += SLAB_THREADS)
-      s_bits[i] = 0u;
+    for (uint32_t i = tid; i < SLAB_WORDS64 / 2; i += SLAB_THREADS)
+      reinterpret_cast<uint4*>(s_bits)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < static_cast<int>(SLAB_WORDS64 / SCAN_WPB))
       s_bsum[tid] = 0u;
     if (tid == 0)
@@ -211,12 +211,14 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const
 // ---- large batches: slab voxelisation and emission in one kernel --------------------------------------------
 // With one workgroup per frame walking the slabs in order, the running voxel count is known inside the workgroup: the
 // voxel records can leave straight from the LDS slab, in key order, and k_scan_b / k_emit (a second trip of the bitmap
-// through global memory, 250 us per 256 frames) disappear.  Per slab: the 64-word groups of the bitmap are dealt
-// round-robin to the 16 waves; pass 1 counts the groups, one wave scans the 256 group totals, pass 2 writes bitmap and
-// rank prefix (coalesced) and emits the group's voxels 64 at a time: slot s finds its word by a binary search over the
-// wave's inclusive popcounts (register shuffles), picks its bit by popcount descent, and the lanes store consecutive ranks.
+// through global memory, 250 us per 256 frames) disappear.  Per slab: the 256-word groups of the bitmap are dealt
+// round-robin to the 16 waves (a lane owns 4 consecutive words: 64-word groups cost 2.6x the rounds on a sparse lattice);
+// pass 1 counts the groups, one wave scans the 64 group totals, pass 2 writes bitmap and rank prefix and emits the group's
+// voxels 64 at a time: slot s finds its owner lane by a binary search over the wave's inclusive counts (register
+// shuffles), its word among the owner's four, its bit by popcount descent, and the lanes store consecutive ranks.
 constexpr int SE_EXTRA_CAP = 4096;
-constexpr int SE_GROUPS = SLAB_WORDS64 / 64;  // 256 groups of 64 words per slab
+constexpr int SE_GWORDS = 256;                      // bitmap words per group: four consecutive words per lane
+constexpr int SE_GROUPS = SLAB_WORDS64 / SE_GWORDS;  // 64 groups per slab
 
 __device__ __forceinline__ int select_bit64(unsigned long long w, uint32_t u)
 {
@@ -237,12 +239,12 @@ __device__ __forceinline__ int select_bit64(unsigned long long w, uint32_t u)
 }
 
 __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, unsigned long long* __restrict__ bitmaps,
-                                                           uint32_t* __restrict__ wprefix_all, VoxelArrays va_all, uint32_t init_count)
+                                                           uint32_t* __restrict__ wprefix_all, VoxelArrays va_all, uint32_t init_count, unsigned long long* __restrict__ prof)
 {
-  __shared__ uint32_t s_bits[SLAB_WORDS64 * 2];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[SLAB_WORDS64 * 2];
   __shared__ uint32_t s_extra[SE_EXTRA_CAP];
   __shared__ uint32_t s_gsum[SE_GROUPS];  // per group: voxel count, then exclusive base
-  __shared__ uint32_t s_ne, s_gbase, s_total;
+  __shared__ uint32_t s_ne, s_gbase, s_total, s_next;
   const uint32_t FRAME = blockIdx.x;
   FrameHdr& h = hdrs[FRAME];
   const uint32_t n_slabs = (h.n_words + SLAB_WORDS64 - 1) / SLAB_WORDS64;
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
   uint32_t* wprefix = wprefix_all + static_cast<size_t>(FRAME) * (g.words_cap + 2);
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   const uint32_t n_round = (n_keys + 63u) & ~63u;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(bm_frame) | reinterpret_cast<uintptr_t>(wprefix)) & 15u) == 0u;  // 16-byte stores allowed for this frame
   const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+  const float inv_dx = 1.0f / static_cast<float>(dx);
   const uint32_t nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
   uint32_t kreg[SLAB_KR];
 #pragma unroll
@@ -266,16 +270,29 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
     kreg[j] = i < n_keys ? keys[i] : 0xffffffffu;
   }
   uint32_t run_base = 0;
+  unsigned long long t_acc[5] = {0, 0, 0, 0, 0}, t_prev = prof ? wall_clock64() : 0ull;  // VOFOD_LDS_PROF diagnostics
+#define SE_STAMP(i)                           \
+  if (prof)                                   \
+  {                                           \
+    const unsigned long long t_now = wall_clock64(); \
+    t_acc[i] += t_now - t_prev;               \
+    t_prev = t_now;                           \
+  }
+  SE_STAMP(0);
   for (uint32_t SLAB = 0; SLAB < n_slabs; SLAB++)
   {
     const uint32_t w_first = SLAB * SLAB_WORDS64;
     const uint32_t n_w = min(SLAB_WORDS64, h.n_words - w_first);
     __syncthreads();  // the previous slab has left the LDS
-    for (uint32_t i = tid; i < SLAB_WORDS64 * 2; i += SLAB_THREADS)
-      s_bits[i] = 0u;
+    for (uint32_t i = tid; i < SLAB_WORDS64 / 2; i += SLAB_THREADS)
+      reinterpret_cast<uint4*>(s_bits)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0)
+    {
       s_ne = 0u;
+      s_next = 0u;
+    }
     __syncthreads();
+    SE_STAMP(1);
     const uint32_t cell0 = SLAB * SLAB_CELLS;
     auto mark = [&](uint32_t kv) -> bool {
       const uint32_t local = kv - cell0;
@@ -324,11 +341,14 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
       stage(mark(kv), kv);
     }
     __syncthreads();
+    SE_STAMP(2);
     const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(s_bits);
-    // pass 1: voxel count of every group (group gi belongs to wave gi % 16)
+    // pass 1: voxel count of every group of 256 words (group gi belongs to wave gi % 16, a lane owns 4 consecutive words)
     for (int gi = wave; gi < SE_GROUPS; gi += SLAB_THREADS / 64)
     {
-      uint32_t c = __popcll(s64[gi * 64 + lane]);
+      const uint4* w4 = reinterpret_cast<const uint4*>(s64 + gi * SE_GWORDS + lane * 4);
+      const uint4 a = w4[0], b = w4[1];
+      uint32_t c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
 #pragma unroll
       for (int sft = 32; sft > 0; sft >>= 1)
         c += __shfl_xor(c, sft);
@@ -338,22 +358,10 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
     __syncthreads();
     if (wave == 0)
     {
-      // exclusive scan of the 256 group totals: 4 per lane
-      uint32_t v4[4], tot = 0;
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-      {
-        v4[q] = s_gsum[lane * 4 + q];
-        tot += v4[q];
-      }
+      // exclusive scan of the 64 group totals
+      const uint32_t tot = s_gsum[lane];
       const uint32_t incl = wave_incl_scan(tot);
-      uint32_t run = incl - tot;
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-      {
-        s_gsum[lane * 4 + q] = run;
-        run += v4[q];
-      }
+      s_gsum[lane] = incl - tot;
       if (lane == 63)
         s_total = incl;
     }
@@ -373,20 +381,60 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
     }
     for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
       extras[s_gbase + i] = s_extra[i];
-    // pass 2: bitmap + rank prefix out, voxel records out
-    for (int gi = wave; gi < SE_GROUPS; gi += SLAB_THREADS / 64)
+    SE_STAMP(3);
+    // pass 2: bitmap + rank prefix out, voxel records out.  The waves draw the groups from a counter: a group of the ground
+    // sheet holds a hundred times the voxels of one in the air, a fixed deal leaves most waves waiting at the barrier.
+    for (;;)
     {
-      const uint32_t w = gi * 64 + lane;
-      const unsigned long long word = s64[w];
-      const uint32_t c = __popcll(word);
+      int gi = 0;
+      if (lane == 0)
+        gi = static_cast<int>(atomicAdd(&s_next, 1u));
+      gi = __shfl(gi, 0);
+      if (gi >= SE_GROUPS)
+        break;
+      const uint32_t w0 = gi * SE_GWORDS + lane * 4;  // first of this lane's four words
+      unsigned long long word[4];
+      uint32_t cw[4], c = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        word[q] = s64[w0 + q];
+        cw[q] = __popcll(word[q]);
+        c += cw[q];
+      }
       const uint32_t incl = wave_incl_scan(c);
       const uint32_t T = __shfl(incl, 63);
       const uint32_t gbase = run_base + s_gsum[gi];
-      if (w < n_w)
       {
-        bm_frame[w_first + w] = word;
-        wprefix[w_first + w] = gbase + incl - c;
+        const uint32_t run = gbase + incl - c;
+        if (w0 + 3 < n_w && vec_ok)  // 32 + 16 bytes per lane, contiguous across the wave
+        {
+          uint4* bo = reinterpret_cast<uint4*>(bm_frame + w_first + w0);
+          bo[0] = make_uint4(static_cast<uint32_t>(word[0]), static_cast<uint32_t>(word[0] >> 32), static_cast<uint32_t>(word[1]), static_cast<uint32_t>(word[1] >> 32));
+          bo[1] = make_uint4(static_cast<uint32_t>(word[2]), static_cast<uint32_t>(word[2] >> 32), static_cast<uint32_t>(word[3]), static_cast<uint32_t>(word[3] >> 32));
+          *reinterpret_cast<uint4*>(wprefix + w_first + w0) = make_uint4(run, run + cw[0], run + cw[0] + cw[1], run + cw[0] + cw[1] + cw[2]);
+        }
+        else  // the lattice's last words
+        {
+          uint32_t r = run;
+          for (int q = 0; q < 4; q++)
+            if (w0 + q < n_w)
+            {
+              bm_frame[w_first + w0 + q] = word[q];
+              wprefix[w_first + w0 + q] = r;
+              r += cw[q];
+            }
+        }
       }
+      if (T == 0)
+        continue;
+      // lattice coordinates of the group's first cell (wave-uniform), the voxels' follow from their offset in the group
+      const uint32_t cell_first = (w_first + gi * SE_GWORDS) * 64u;
+      const uint32_t gk2 = cell_first / dxy;
+      const uint32_t grem = cell_first - gk2 * dxy;
+      const uint32_t gk1 = grem / dx;
+      const uint32_t gk0 = grem - gk1 * dx;
+      const uint32_t cpack = cw[0] | (cw[1] << 8) | (cw[2] << 16);  // counts of the lane's first three words (each <= 64)
       for (uint32_t s0 = 0; s0 < T; s0 += 64)
       {
         const uint32_t sidx = s0 + lane;
@@ -403,17 +451,40 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
             hi = mid;
         }
         const int owner = lo;
-        const uint32_t oincl = __shfl(incl, owner), oc = __shfl(c, owner);
-        const unsigned long long oword = __shfl(word, owner);
+        const uint32_t oincl = __shfl(incl, owner), oc = __shfl(c, owner), opack = __shfl(cpack, owner);
         if (sidx < T)
         {
-          const int bit = select_bit64(oword, sidx - (oincl - oc));
-          const uint32_t key = (w_first + gi * 64 + owner) * 64u + bit;
+          uint32_t u = sidx - (oincl - oc);  // index among the owner's voxels
+          int q = 0;
+#pragma unroll
+          for (int t = 0; t < 3; t++)
+          {
+            const uint32_t ct = (opack >> (8 * t)) & 0xffu;
+            if (q == t && u >= ct)
+            {
+              u -= ct;
+              q = t + 1;
+            }
+          }
+          const uint32_t wi = gi * SE_GWORDS + owner * 4 + q;
+          const int bit = select_bit64(s64[wi], u);
+          const uint32_t off = (static_cast<uint32_t>(owner) * 4u + q) * 64u + bit;  // < 16384
+          const uint32_t key = cell_first + off;
           const uint32_t rank = gbase + sidx;
-          const int k2 = key / dxy;
-          const int rem = key - k2 * dxy;
-          const int k1 = rem / dx;
-          const int k0 = rem - k1 * dx;
+          // (gk0 + off) / dx by float reciprocal: the operands are below 2^14 + dx, the correction steps make it exact
+          const uint32_t x = gk0 + off;
+          uint32_t qd = static_cast<uint32_t>(static_cast<float>(x) * inv_dx);
+          qd -= (qd * static_cast<uint32_t>(dx) > x) ? 1u : 0u;
+          qd += ((qd + 1u) * static_cast<uint32_t>(dx) <= x) ? 1u : 0u;
+          const int k0 = static_cast<int>(x - qd * dx);
+          uint32_t y = gk1 + qd;
+          int k2 = static_cast<int>(gk2);
+          while (y >= static_cast<uint32_t>(h.div_b[1]))  // a group spans a few dozen rows: rarely more than one plane boundary
+          {
+            y -= h.div_b[1];
+            k2++;
+          }
+          const int k1 = static_cast<int>(y);
           float4 p;
           p.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
           p.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
@@ -435,9 +506,14 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
       }
     }
     run_base += slab_total;
+    SE_STAMP(4);
   }
   if (tid == 0)
     h.V = run_base;
+  if (prof && tid == 0)
+    for (int i = 0; i < 5; i++)
+      prof[static_cast<size_t>(FRAME) * 16 + i] = t_acc[i];
+#undef SE_STAMP
 }
 
 // weights: every voxel starts at 1 (k_emit); each extra point adds 1 to its voxel

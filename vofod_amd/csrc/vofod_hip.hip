@@ -820,10 +820,20 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     // VOFOD_SLAB_EMIT=0 keeps the separate emission kernels for every batch size
     static const bool slab_emit_on = !(std::getenv("VOFOD_SLAB_EMIT") && std::atoi(std::getenv("VOFOD_SLAB_EMIT")) == 0);
     ws.bitmap_clean = false;
+    static unsigned long long* d_prof_se = nullptr;
+    if (!d_prof_se && std::getenv("VOFOD_LDS_PROF"))
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof_se), sizeof(unsigned long long) * 16 * 4096));
     if (slab_emit_on && n >= 128)
     {
       // batches that fill the chip: one workgroup per frame walks the slabs in order and emits the voxel records itself
-      KLAUNCH(h, k_slab_emit, dim3(n), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va, 1u | lean_bit);
+      KLAUNCH(h, k_slab_emit, dim3(n), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va, 1u | lean_bit, d_prof_se);
+      if (d_prof_se)
+      {
+        unsigned long long t[16];
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(t, d_prof_se, sizeof(t), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[k_slab_emit] keys %.1f | zero %.1f mark %.1f count+scan %.1f out+emit %.1f us (all slabs of frame 0)\n", t[0] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[4] * 0.01);
+      }
     }
     else
     {
