@@ -251,8 +251,6 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
       while ((p = va.parent[root]) != root)
         root = p;
     }
-    else if (SRC == 2)
-      root = labels[v];  // written by k_brick_ccl_lds
     else
     {
       // brick path: k_brick_root left every brick pointing at its representative, whose bcmin is the component's label
@@ -261,8 +259,7 @@ __global__ __launch_bounds__(256) void k_flatten(const GridParams g, const Frame
       const uint32_t b = brick_of(h, ijk[0], ijk[1], ijk[2], bit);
       root = ba.bcmin[ba.bparent[b]];
     }
-    if (SRC != 2)
-      labels[v] = root;
+    labels[v] = root;
   }
   // hasCloseTo through the dilated occupancy image (k_dilate), when the caller has one: the voxel centre is rebuilt with
   // k_emit's expression, its map cell looked up, and one flag store per run of equal roots marks the cluster close

@@ -1031,14 +1031,15 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     else
       KLAUNCH(h, k_brick_union<1>, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
     KLAUNCH(h, k_brick_root, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.ba, ws.d_bitmaps, ws.d_wprefix);
-    KLAUNCH(h, k_flatten<1>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap, h->mg, nullptr, nullptr, nullptr, 0);
+    KLAUNCH(h, k_flatten<1>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, ws.bricks_cap, h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows);
     KLAUNCH(h, k_brick_clear, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.ba);
   }
   else
   {
     KLAUNCH(h, k_union<2>, fgrid(g, gv), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va);
-    KLAUNCH(h, k_flatten<0>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, 0u, h->mg, nullptr, nullptr, nullptr, 0);
+    KLAUNCH(h, k_flatten<0>, fgrid(g, gv), dim3(256), g, ws.d_hdrs, ws.va, ws.d_labels, ws.ba, 0u, h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows);
   }
+  ws.closefar_fused = mapclose != nullptr;  // k_flatten answered hasCloseTo through the dilated image
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
 }
