@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from vofod_amd import capi, synth
-from vofod_amd.detector import cluster, voxel_grid_counted, voxel_grid_weighted
+from vofod_amd.detector import ScanData, cluster, voxel_grid_counted, voxel_grid_weighted
 
 from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair, sync_maps
 
@@ -255,6 +255,45 @@ def test_large_batch_takes_the_fused_slab_emission(oracle, hip):
     for x, y in zip(ga, gb):
         assert_scan_debug_equal(x, y)
     assert sum(len(x["weighted"]) for x in ga) > 136 * 1000
+
+
+def _dense_scan(sensor, seed, extent, empty=False):
+    """an organised scan whose points are uniform in a box around the sensor (no LiDAR geometry): nearly every point
+    survives the crops, many points share a voxel"""
+    h, w, _, _ = synth.SENSORS[sensor]
+    n = h * w
+    rng = np.random.default_rng(seed)
+    if empty:
+        x = y = z = np.zeros(n, dtype=np.float32)  # (0,0,0) sits inside the exclude box: every point is dropped
+    else:
+        x = rng.uniform(-extent, extent, n).astype(np.float32)
+        y = rng.uniform(-extent, extent, n).astype(np.float32)
+        z = rng.uniform(-2.0, 1.0, n).astype(np.float32)
+    return ScanData(x=x, y=y, z=z.copy(), width=w, height=h, stride_bytes=4)
+
+
+@pytest.mark.parametrize("n_frames", [6, 130])
+def test_batches_of_dense_and_empty_frames(oracle, hip, n_frames):
+    """stress of the slab voxeliser's side paths: key lists longer than the register file (> 48 Ki survivors), more
+    extras than the LDS staging area, an empty frame in the middle of a batch; both batch forms (k_slab / k_slab_emit)"""
+    sensor = "os1-128" if n_frames == 6 else "os1-16"
+    ref, dev = make_pair(oracle, hip, sensor, 0.25, max_batch=n_frames)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    pose = synth.make_pose(3)
+    kinds = [_dense_scan(sensor, 1, 12.0), _dense_scan(sensor, 2, 3.0), _dense_scan(sensor, 3, 1.0, empty=True), _dense_scan(sensor, 4, 25.0)]
+    scans = [kinds[i % 4] for i in range(n_frames)]
+    tfs = np.stack([pose] * n_frames).astype(np.float32)
+    da, pa, ga = ref.process_batch(scans, tfs, debug=True)
+    db, pb, gb = dev.process_batch(scans, tfs, debug=True)
+    np.testing.assert_array_equal(pb, pa)
+    assert_detections_equal(da, db)
+    for x, y in zip(ga, gb):
+        assert_scan_debug_equal(x, y)
+    assert ga[2]["n_input_after_crop"] == 0 and len(ga[2]["weighted"]) == 0
+    if n_frames == 6:
+        assert ga[0]["n_input_after_crop"] > 100_000  # beyond the 49 152 keys a workgroup keeps in registers
+        assert ga[1]["n_input_after_crop"] - len(ga[1]["weighted"]) > 50_000  # extras far beyond the LDS staging area
 
 
 def test_error_paths(oracle, hip):
