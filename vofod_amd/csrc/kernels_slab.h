@@ -20,8 +20,14 @@
 namespace vk
 {
 
-constexpr int KEY_THREADS = 1024;
-constexpr int KEY_PPT = 8;  // points per thread
+#ifndef VOFOD_KEY_THREADS
+#define VOFOD_KEY_THREADS 256  /* 256 x 8: 121 us per 256 frames; 512 x 8: 149; 1024 x 8: 160; 256 x 16: 164 */
+#endif
+#ifndef VOFOD_KEY_PPT
+#define VOFOD_KEY_PPT 8
+#endif
+constexpr int KEY_THREADS = VOFOD_KEY_THREADS;
+constexpr int KEY_PPT = VOFOD_KEY_PPT;  // points per thread
 constexpr int SLAB_THREADS = 1024;
 constexpr uint32_t SLAB_WORDS64 = 16384;              // 64-bit bitmap words per slab = 128 KB of LDS
 constexpr uint32_t SLAB_CELLS = SLAB_WORDS64 * 64u;   // 1 Mi cells

@@ -110,28 +110,35 @@ __global__ void k_init_hdr(FrameHdr* hdrs)
 }
 
 // K1-K4a: crop + transform + crop fused with pcl::getMinMax3D (voxel_grid_weighted.cpp:58).
+constexpr int BBOX_PPT = 8;  // points per thread and round
 __global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridParams g, FrameHdr* hdrs)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
-  (void)GX;
   const FrameArgs& a = args[FRAME];
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
   uint32_t cnt = 0;
-  for (uint32_t i = BX * blockDim.x + threadIdx.x; i < a.n; i += GX * blockDim.x)
+  // a workgroup covers BBOX_PPT * 256 consecutive points per round (one round when the launch has a workgroup per 2048
+  // points); the unrolled inner loop keeps all the round's loads in flight
+  for (uint32_t base = BX * 256u * BBOX_PPT; base < a.n; base += GX * 256u * BBOX_PPT)
   {
-    float q[3];
-    if (!fetch_point(a, g, i, q))
-      continue;
-    cnt++;
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+    for (int j = 0; j < BBOX_PPT; j++)
     {
-      const int o = f2ord(q[c]);
-      mn[c] = min(mn[c], o);
-      mx[c] = max(mx[c], o);
+      const uint32_t i = base + j * 256u + threadIdx.x;
+      float q[3];
+      if (i >= a.n || !fetch_point(a, g, i, q))
+        continue;
+      cnt++;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        const int o = f2ord(q[c]);
+        mn[c] = min(mn[c], o);
+        mx[c] = max(mx[c], o);
+      }
     }
   }
 #pragma unroll
