@@ -250,7 +250,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[SLAB_WORDS64 * 2];
   __shared__ uint32_t s_extra[SE_EXTRA_CAP];
   __shared__ uint32_t s_gsum[SE_GROUPS];  // per group: voxel count, then exclusive base
-  __shared__ uint32_t s_ne, s_gbase, s_total, s_next;
+  __shared__ uint32_t s_ne, s_total, s_next;
   const uint32_t FRAME = blockIdx.x;
   FrameHdr& h = hdrs[FRAME];
   const uint32_t n_slabs = (h.n_words + SLAB_WORDS64 - 1) / SLAB_WORDS64;
@@ -372,8 +372,6 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
         s_total = incl;
     }
     const uint32_t ne = min(s_ne, static_cast<uint32_t>(SE_EXTRA_CAP));
-    if (tid == 64)
-      s_gbase = ne ? atomicAdd(&sa.counts[2 * FRAME + 1], ne) : 0u;
     __syncthreads();
     const uint32_t slab_total = s_total;
     if (run_base + slab_total > g.vox_cap)
@@ -385,8 +383,6 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
       }
       return;
     }
-    for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
-      extras[s_gbase + i] = s_extra[i];
     SE_STAMP(3);
     // pass 2: bitmap + rank prefix out, voxel records out.  The waves draw the groups from a counter: a group of the ground
     // sheet holds a hundred times the voxels of one in the air, a fixed deal leaves most waves waiting at the barrier.
@@ -510,6 +506,17 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
           }
         }
       }
+    }
+    // the staged extras add to their voxels' weights right here: the records were just written by this workgroup (they sit
+    // in L2), the rank comes from the prefix entry written above and the slab's word in LDS.  Only extras beyond the staging
+    // area went to the global list (k_count_extras).
+    __syncthreads();
+    for (uint32_t i = tid; i < ne; i += SLAB_THREADS)
+    {
+      const uint32_t local = s_extra[i] - cell0;
+      const uint32_t w = local >> 6;
+      const uint32_t rank = wprefix[w_first + w] + __popcll(s64[w] & ((1ull << (local & 63u)) - 1ull));
+      atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[rank].w), 1u);
     }
     run_base += slab_total;
     SE_STAMP(4);

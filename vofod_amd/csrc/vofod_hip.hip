@@ -843,7 +843,8 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
       KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
       KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit);
     }
-    KLAUNCH(h, k_count_extras, fgrid(g, 24), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
+    // after k_slab_emit only the extras beyond its LDS staging area are left (none on ordinary scans)
+    KLAUNCH(h, k_count_extras, fgrid(g, (slab_emit_on && n >= 128) ? 4 : 24), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
     HIPCHK(hipGetLastError());
     return VOFOD_OK;
   }
