@@ -222,7 +222,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab(const GridParams g, const
 // pass 1 counts the groups, one wave scans the 64 group totals, pass 2 writes bitmap and rank prefix and emits the group's
 // voxels 64 at a time: slot s finds its owner lane by a binary search over the wave's inclusive counts (register
 // shuffles), its word among the owner's four, its bit by popcount descent, and the lanes store consecutive ranks.
-constexpr int SE_EXTRA_CAP = 4096;
+constexpr int SE_EXTRA_CAP = 7168;  // extras staged in LDS per slab (the ground slab of an OS1-128 scan holds ~5 k)
 constexpr int SE_GWORDS = 256;                      // bitmap words per group: four consecutive words per lane
 constexpr int SE_GROUPS = SLAB_WORDS64 / SE_GWORDS;  // 64 groups per slab
 
