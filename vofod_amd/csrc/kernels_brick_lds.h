@@ -68,16 +68,20 @@ __device__ __forceinline__ uint32_t lb_oct8(unsigned long long W)
   return (lo & 1u) | ((lo >> 1) & 2u) | ((lo >> 6) & 4u) | ((lo >> 7) & 8u) | ((hi & 1u) << 4) | (((hi >> 2) & 1u) << 5) | (((hi >> 8) & 1u) << 6) | (((hi >> 10) & 1u) << 7);
 }
 
+// any bit (po, qo) of the 8x8 matrix m with po in A8 and qo in B8?  Branch-free on the two 32-bit halves: the rows of A8
+// become all-ones bytes, B8 is replicated into every byte.
+__device__ __forceinline__ uint32_t lb_rowsel(uint32_t A8x01010101, uint32_t pick)
+{
+  const uint32_t x = A8x01010101 & pick;               // byte r holds bit (r or r + 4) of A8, or nothing
+  const uint32_t t = ((x + 0x7f7f7f7fu) | x) & 0x80808080u;  // high bit of every non-zero byte
+  return (t >> 7) * 0xffu;
+}
 __device__ __forceinline__ bool lb_octtest(unsigned long long m, uint32_t A8, uint32_t B8)
 {
-  bool hit = false;
-  while (A8)
-  {
-    const int po = __ffs(static_cast<int>(A8)) - 1;
-    A8 &= A8 - 1;
-    hit |= ((static_cast<uint32_t>(m >> (8 * po)) & B8) & 0xffu) != 0u;
-  }
-  return hit;
+  const uint32_t a = A8 * 0x01010101u, cols = B8 * 0x01010101u;
+  const uint32_t lo = static_cast<uint32_t>(m) & lb_rowsel(a, 0x08040201u) & cols;
+  const uint32_t hi = static_cast<uint32_t>(m >> 32) & lb_rowsel(a, 0x80402010u) & cols;
+  return (lo | hi) != 0u;
 }
 
 __device__ __forceinline__ uint32_t lb_shift(uint32_t m, int sh) { return sh >= 0 ? (sh < 32 ? m >> sh : 0u) : m << (-sh); }
@@ -374,19 +378,26 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
       const uint32_t xyz = live ? s_xyz[t] : 0u;
       const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
       const int lo = max(bx - R, 0), hi = min(bx + R, nbx - 1);
-      for (int row0 = 0; row0 < n_rows; row0 += LB_LANES)
+      // both rows of the lane are probed before either is consumed: their LDS reads overlap
+      constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
+      static_assert(RPL == 2, "the reservation below adds up two rows per lane");
+      uint32_t winv[RPL], rawv[RPL], nbv[RPL];
+      unsigned long long ovv[RPL];
+      int shv[RPL];
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++)
       {
-        const int row = row0 + sub;
-        uint32_t win = 0, raw = 0, nodebase = 0;
-        unsigned long long ovec = 0;
-        int shift = 0;
+        const int row = rr * LB_LANES + sub;
+        winv[rr] = rawv[rr] = nbv[rr] = 0;
+        ovv[rr] = 0;
+        shv[rr] = 0;
         if (live && row < n_rows)
         {
           const unsigned long long q0 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[0];
           const unsigned long long q1 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[1];
           const int ddy = static_cast<int8_t>(q0 & 0xffu), ddz = static_cast<int8_t>((q0 >> 8) & 0xffu);
           const uint32_t rw_valid = static_cast<uint32_t>(q0 >> 16) & 0xffu;
-          ovec = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
+          ovv[rr] = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
           const int ny = by + ddy, nz = bz + ddz;
           if (ny >= 0 && ny < nby && nz < nbz)
           {
@@ -395,25 +406,30 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
             const uint32_t w_lo = s_bits[wi], w_hi = s_bits[wi + 1];
             const uint32_t pre = s_pre[wi];
             const unsigned long long two = static_cast<unsigned long long>(w_lo) | (static_cast<unsigned long long>(w_hi) << 32);
-            raw = static_cast<uint32_t>(two >> sh) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick first + j
-            shift = lo - (bx - R);
-            win = (raw << shift) & rw_valid;  // bit s: the brick at dx = s - R is occupied and in the half stencil
-            nodebase = pre + __popc(w_lo & ((1u << sh) - 1u));  // node of the first occupied brick at or after `first`
+            rawv[rr] = static_cast<uint32_t>(two >> sh) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick first + j
+            shv[rr] = lo - (bx - R);
+            winv[rr] = (rawv[rr] << shv[rr]) & rw_valid;  // bit s: the brick at dx = s - R is occupied and in the half stencil
+            nbv[rr] = pre + __popc(w_lo & ((1u << sh) - 1u));  // node of the first occupied brick at or after `first`
           }
         }
-        // one reservation per wave
-        const uint32_t k = __popc(win);
-        const uint32_t incl = wave_incl_scan(k);
-        uint32_t base = 0;
-        if (lane == 63 && incl)
-          base = atomicAdd(&s_nh, incl);
-        uint32_t pos = __shfl(base, 63) + incl - k;
+      }
+      // one reservation per wave for both rows
+      const uint32_t k = __popc(winv[0]) + (RPL > 1 ? __popc(winv[RPL - 1]) : 0u);
+      const uint32_t incl = wave_incl_scan(k);
+      uint32_t base = 0;
+      if (lane == 63 && incl)
+        base = atomicAdd(&s_nh, incl);
+      uint32_t pos = __shfl(base, 63) + incl - k;
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++)
+      {
+        uint32_t win = winv[rr];
         while (win)
         {
           const int s = __ffs(static_cast<int>(win)) - 1;
           win &= win - 1;
-          const uint32_t o = static_cast<uint32_t>(ovec >> (8 * s)) & 0xffu;
-          const uint32_t t2 = nodebase + __popc(raw & ((1u << (s - shift)) - 1u));
+          const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * s)) & 0xffu;
+          const uint32_t t2 = nbv[rr] + __popc(rawv[rr] & ((1u << (s - shv[rr])) - 1u));
           if (pos < hcap)
             hits[pos] = t | (t2 << 13) | (o << 26);
           pos++;
@@ -435,42 +451,67 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
   if (prof && tid == 0)
     prof[static_cast<size_t>(FRAME) * 16 + 7] = wall_clock64();
   constexpr int HU = 8;
-  for (uint32_t i0 = tid; i0 < nh; i0 += LB_THREADS * HU)
+  // a lane takes HU consecutive hits: they mostly share the brick t (the list is in D-a's order), whose root is then found once
+  for (uint32_t i0 = tid * HU; i0 < nh; i0 += LB_THREADS * HU)
   {
     uint32_t hv[HU];
 #pragma unroll
     for (int u = 0; u < HU; u++)
     {
-      const uint32_t i = i0 + u * LB_THREADS;
+      const uint32_t i = i0 + u;
       hv[u] = i < nh ? __builtin_nontemporal_load(&hits[i]) : 0xffffffffu;
+    }
+    // staged so that the LDS reads of the round's hits are issued together (16 waves per CU hide little latency)
+    unsigned long long Aw[HU], Bw[HU], Ms[HU], Mm[HU];
+    uint32_t pa[HU], pb[HU];
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      const bool ok = hv[u] != 0xffffffffu;
+      const uint32_t t = ok ? hv[u] & 8191u : 0u, t2 = ok ? (hv[u] >> 13) & 8191u : 0u, o = ok ? hv[u] >> 26 : 0u;
+      Aw[u] = s_word[t];
+      Bw[u] = s_word[t2];
+      Ms[u] = s_tab.oct[2 * o];
+      Mm[u] = s_tab.oct[2 * o + 1];
+      pa[u] = lb_ld16(s_par, t);
+      pb[u] = lb_ld16(s_par, t2);
+    }
+    uint32_t kind[HU];  // 0 nothing, 1 accepted by the octant matrices, 2 open
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      const uint32_t A8 = lb_oct8(Aw[u]), B8 = lb_oct8(Bw[u]);
+      kind[u] = hv[u] == 0xffffffffu ? 0u : lb_octtest(Ms[u], A8, B8) ? 1u : lb_octtest(Mm[u], A8, B8) ? 2u : 0u;
     }
 #pragma unroll
     for (int u = 0; u < HU; u++)
     {
-      if (hv[u] == 0xffffffffu)
-        continue;
-      const uint32_t t = hv[u] & 8191u, t2 = (hv[u] >> 13) & 8191u, o = hv[u] >> 26;
-      const unsigned long long A = s_word[t], B = s_word[t2];
-      const uint32_t A8 = lb_oct8(A), B8 = lb_oct8(B);
-      if (!lb_octtest(s_tab.oct[2 * o], A8, B8))
+      // the open pairs of the round: one reservation per wave
+      const unsigned long long m = __ballot(kind[u] == 2u);
+      if (m)
       {
-        if (lb_octtest(s_tab.oct[2 * o + 1], A8, B8))
-        {
-          // one reservation per group of lanes that arrive here together
-          const unsigned long long m = __ballot(1);
-          const int leader = __ffsll(static_cast<long long>(m)) - 1;
-          uint32_t base = 0;
-          if (lane == leader)
-            base = atomicAdd(&s_no, static_cast<uint32_t>(__popcll(m)));
-          base = __shfl(base, leader);
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&s_no, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader);
+        if (kind[u] == 2u)
           opens[base + __popcll(m & ((1ull << lane) - 1ull))] = hv[u];
-        }
-        continue;
       }
-      const uint32_t pa = lb_ld16(s_par, t), pb = lb_ld16(s_par, t2);
-      if (pa == pb)
+    }
+    uint32_t cur_t = 0xffffffffu, cur_root = 0;
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      if (kind[u] != 1u || pa[u] == pb[u])
         continue;
-      uint32_t ra = pa == t ? t : lb_find(s_par, pa), rb = pb == t2 ? t2 : lb_find(s_par, pb);
+      const uint32_t t = hv[u] & 8191u, t2 = (hv[u] >> 13) & 8191u;
+      cur_root = lb_find(s_par, t == cur_t ? cur_root : t);
+      cur_t = t;
+      uint32_t ra = cur_root, rb = lb_find(s_par, t2);
+      if (ra == rb)
+        continue;
+      cur_root = min(ra, rb);  // whichever way the hooks below go, the smaller root ends above both
       while (ra != rb)
       {
         if (ra < rb)
@@ -515,9 +556,22 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
     prof[static_cast<size_t>(FRAME) * 16 + 10] = no;
     prof[static_cast<size_t>(FRAME) * 16 + 11] = n;
   }
-  for (uint32_t i = tid; i < no; i += LB_THREADS)
+  constexpr int OU = 8;  // open pairs fetched per lane and round: independent loads in flight
+  for (uint32_t i0 = tid; i0 < no; i0 += LB_THREADS * OU)
   {
-    const uint32_t hv = opens[i];
+    uint32_t ov[OU];
+#pragma unroll
+    for (int u = 0; u < OU; u++)
+    {
+      const uint32_t i = i0 + u * LB_THREADS;
+      ov[u] = i < no ? opens[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < OU; u++)
+    {
+    if (ov[u] == 0xffffffffu)
+      continue;
+    const uint32_t hv = ov[u];
     const uint32_t t = hv & 8191u, t2 = (hv >> 13) & 8191u;
     uint32_t ra = lb_find(s_par, t), rb = lb_find(s_par, t2);
     if (ra == rb)
@@ -541,6 +595,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
       if (old == ra)
         break;
       ra = old;
+    }
     }
   }
   __syncthreads();
@@ -568,9 +623,24 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
       const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
       my_w[r] = s_word[i];
       const int bit = __ffsll(static_cast<long long>(my_w[r])) - 1;
-      const uint32_t key = static_cast<uint32_t>(((4 * bz + (bit >> 4)) * h.div_b[1] + (4 * by + ((bit >> 2) & 3))) * h.div_b[0] + 4 * bx + (bit & 3));
-      my_min[r] = rank_of(bm, wprefix, key);
+      my_min[r] = static_cast<uint32_t>(((4 * bz + (bit >> 4)) * h.div_b[1] + (4 * by + ((bit >> 2) & 3))) * h.div_b[0] + 4 * bx + (bit & 3));  // key for now
     }
+  }
+  {
+    // the ranks of those keys: all of a lane's bitmap / prefix words are fetched together
+    unsigned long long bw[LB_MAX / LB_THREADS];
+    uint32_t pw[LB_MAX / LB_THREADS];
+#pragma unroll
+    for (int r = 0; r < LB_MAX / LB_THREADS; r++)
+    {
+      const bool ok = my_root[r] != 0xffffffffu;
+      bw[r] = ok ? bm[my_min[r] >> 6] : 0ull;
+      pw[r] = ok ? wprefix[my_min[r] >> 6] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < LB_MAX / LB_THREADS; r++)
+      if (my_root[r] != 0xffffffffu)
+        my_min[r] = pw[r] + __popcll(bw[r] & ((1ull << (my_min[r] & 63u)) - 1ull));
   }
   __syncthreads();  // roots and words are in registers: flatten the forest, turn the words into the minima
 #pragma unroll
@@ -647,11 +717,12 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
   for (int r = 0; r < LB_MAX / LB_THREADS; r++)
   {
     const uint32_t i = r * LB_THREADS + tid;
-    if (i >= n)
+    if (r * LB_THREADS + (tid & ~63) >= n)  // the whole wave is past the last brick
       continue;
-    const unsigned long long W = my_w[r];
-    const uint32_t c = s_cidx[my_root[r]];
-    const uint32_t xyz = s_xyz[i];
+    const bool live = i < n;  // lanes past the last brick stay in the shuffles below with neutral values
+    const unsigned long long W = live ? my_w[r] : 1ull;
+    const uint32_t c = live ? s_cidx[my_root[r]] : 0xffffffffu;
+    const uint32_t xyz = live ? s_xyz[i] : 0u;
     const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
     // extents of the set bits along x, y, z (bit p = x + 4y + 16z)
     unsigned long long t = W | (W >> 16) | (W >> 32) | (W >> 48);
@@ -667,7 +738,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
     const uint32_t cnt = __popcll(W);
     // hasCloseTo through the dilated map image, until the component is known to be close
     bool hit = false;
-    if (mapclose && !(c < LB_ST_ROWS ? st_close[c] : 0u))
+    if (live && mapclose && !(c < LB_ST_ROWS ? st_close[c] : 0u))
     {
       unsigned long long a = W;
       while (a && !hit)
@@ -704,6 +775,50 @@ __global__ __launch_bounds__(LB_THREADS) void k_brick_ccl_lds(const GridParams g
           hit |= Lq[q] != ~0ull && ((wq[q] >> (Lq[q] & 63)) & 1ull);
       }
     }
+    // wave level: the lanes hold consecutive bricks, mostly of one component (the ground sheet): its lanes are reduced with
+    // shuffles and one lane adds the aggregate; LDS atomics on one row would otherwise serialise (4 cycles each)
+    {
+      const uint32_t lead = __shfl(c, __ffsll(static_cast<long long>(__ballot(1))) - 1);
+      const bool same = c == lead && c < LB_ST_ROWS;
+      const unsigned long long m_same = __ballot(same);
+      if (__popcll(m_same) >= 8)
+      {
+        uint32_t rc = same ? cnt : 0u;
+        int rlo[3], rhi[3];
+        for (int a = 0; a < 3; a++)
+        {
+          rlo[a] = same ? lo[a] : 0x7fffffff;
+          rhi[a] = same ? hi[a] : static_cast<int>(0x80000000u);
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1)
+        {
+          rc += __shfl_xor(rc, sft);
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+          {
+            rlo[a] = min(rlo[a], __shfl_xor(rlo[a], sft));
+            rhi[a] = max(rhi[a], __shfl_xor(rhi[a], sft));
+          }
+        }
+        const bool any_hit = __ballot(same && hit) != 0ull;
+        if (lane == __ffsll(static_cast<long long>(m_same)) - 1)
+        {
+          atomicAdd(&st_cnt[lead], rc);
+          if (any_hit)
+            st_close[lead] = 1u;
+          for (int a = 0; a < 3; a++)
+          {
+            atomicMin(&st_box[6 * lead + a], rlo[a]);
+            atomicMax(&st_box[6 * lead + 3 + a], rhi[a]);
+          }
+        }
+        if (same)
+          continue;  // folded into the aggregate
+      }
+    }
+    if (!live)
+      continue;
     if (c < LB_ST_ROWS)
     {
       atomicAdd(&st_cnt[c], cnt);
