@@ -277,6 +277,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
   }
   uint32_t run_base = 0;
   unsigned long long t_acc[5] = {0, 0, 0, 0, 0}, t_prev = prof ? wall_clock64() : 0ull;  // VOFOD_LDS_PROF diagnostics
+  const unsigned long long t_start = t_prev;
 #define SE_STAMP(i)                           \
   if (prof)                                   \
   {                                           \
@@ -341,10 +342,20 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
           stage(ex[u], kreg[j0 + u]);
       }
     }
-    for (uint32_t i0 = SLAB_KR * SLAB_THREADS + tid; i0 < n_round; i0 += SLAB_THREADS)
+    for (uint32_t i0 = SLAB_KR * SLAB_THREADS + tid; i0 < n_round; i0 += SLAB_THREADS * KB)  // lists beyond the register file
     {
-      const uint32_t kv = i0 < n_keys ? keys[i0] : 0xffffffffu;
-      stage(mark(kv), kv);
+      uint32_t kv[KB];
+      bool ex[KB];
+#pragma unroll
+      for (int u = 0; u < KB; u++)
+        kv[u] = i0 + u * SLAB_THREADS < n_keys ? keys[i0 + u * SLAB_THREADS] : 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < KB; u++)
+        ex[u] = mark(kv[u]);
+#pragma unroll
+      for (int u = 0; u < KB; u++)
+        if (i0 + u * SLAB_THREADS - tid < n_round)  // wave-uniform
+          stage(ex[u], kv[u]);
     }
     __syncthreads();
     SE_STAMP(2);
@@ -524,8 +535,13 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_slab_emit(const GridParams g, 
   if (tid == 0)
     h.V = run_base;
   if (prof && tid == 0)
+  {
     for (int i = 0; i < 5; i++)
       prof[static_cast<size_t>(FRAME) * 16 + i] = t_acc[i];
+    prof[static_cast<size_t>(FRAME) * 16 + 5] = t_start;
+    prof[static_cast<size_t>(FRAME) * 16 + 6] = wall_clock64();
+    prof[static_cast<size_t>(FRAME) * 16 + 7] = n_keys;
+  }
 #undef SE_STAMP
 }
 

@@ -833,6 +833,36 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(t, d_prof_se, sizeof(t), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[k_slab_emit] keys %.1f | zero %.1f mark %.1f count+scan %.1f out+emit %.1f us (all slabs of frame 0)\n", t[0] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[4] * 0.01);
+        std::vector<unsigned long long> all(16 * n);
+        HIPCHK(hipMemcpy(all.data(), d_prof_se, sizeof(unsigned long long) * 16 * n, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double dmin = 1e9, dmax = 0, dsum = 0, smax = 0;
+        for (uint32_t f = 0; f < n; f++)
+        {
+          t0 = std::min(t0, all[16 * f + 5]);
+          t1 = std::max(t1, all[16 * f + 6]);
+        }
+        for (uint32_t f = 0; f < n; f++)
+        {
+          const double d = (all[16 * f + 6] - all[16 * f + 5]) * 0.01;
+          dmin = std::min(dmin, d);
+          dmax = std::max(dmax, d);
+          dsum += d;
+          smax = std::max(smax, (all[16 * f + 5] - t0) * 0.01);
+        }
+        {
+          std::vector<std::pair<double, uint32_t>> byd;
+          for (uint32_t f = 0; f < n; f++)
+            byd.push_back({(all[16 * f + 6] - all[16 * f + 5]) * 0.01, f});
+          std::sort(byd.begin(), byd.end());
+          for (size_t q : {size_t(0), byd.size() / 4, byd.size() / 2, 3 * byd.size() / 4, byd.size() - 1})
+          {
+            const uint32_t f = byd[q].second;
+            std::fprintf(stderr, "[k_slab_emit]   frame %u: %.1f us, keys %llu, zero %.1f mark %.1f count %.1f emit %.1f\n", f, byd[q].first, all[16 * f + 7], all[16 * f + 1] * 0.01, all[16 * f + 2] * 0.01,
+                         all[16 * f + 3] * 0.01, all[16 * f + 4] * 0.01);
+          }
+        }
+        std::fprintf(stderr, "[k_slab_emit] %u workgroups: span %.1f us, per-workgroup min %.1f mean %.1f max %.1f us, latest start +%.1f us\n", n, (t1 - t0) * 0.01, dmin, dsum / n, dmax, smax);
       }
     }
     else
