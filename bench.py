@@ -247,6 +247,7 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_setbits": 12.0 * n_pts * F,
         "k_key": 12.0 * n_pts * F,
         "k_slab": 4.0 * V * F,             # the surviving points' keys (at least one per voxel)
+        "k_slab_emit": 28.0 * V * F,       # keys in (>= 4*V), voxel records out (pts 16 + key 4 + brick code 4)
         "k_brick_ccl_lds": 16.0 * V * F,   # the whole neighbourhood + link stage of the clustering, inside LDS
         "k_flatten<2>": 8.0 * V * F,
         "k_count": 12.0 * n_pts * F,
