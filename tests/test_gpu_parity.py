@@ -239,9 +239,11 @@ def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, 
         np.testing.assert_array_equal(g1[1], w1[1])
 
 
-def test_large_batch_takes_the_fused_slab_emission(oracle, hip):
-    """>= 128 frames per batch: k_slab_emit (bitmap slab in LDS -> voxel records) replaces k_slab + k_scan_b + k_emit"""
-    ref, dev = make_pair(oracle, hip, "os1-16", 0.25, max_batch=136)
+@pytest.mark.parametrize("voxel_size", [0.25, 0.5])
+def test_large_batch_takes_the_fused_slab_emission(oracle, hip, voxel_size):
+    """>= 128 frames per batch: k_slab_emit (bitmap slab in LDS -> voxel records) replaces k_slab + k_scan_b + k_emit;
+    0.25 m: brick clustering in LDS follows, 0.5 m: the voxel-level clustering kernels (they read the whole prefix array)"""
+    ref, dev = make_pair(oracle, hip, "os1-16", voxel_size, max_batch=136)
     for d in (ref, dev):
         synth.seed_ground(d)
     scene = synth.make_scene(43, n_targets=2)
