@@ -29,15 +29,14 @@ def pack_detections(dets: np.ndarray, per_frame: np.ndarray, out: np.ndarray | N
         out = np.zeros((n, FRAME_F64), dtype=np.float64)
     else:
         out[:] = 0
+    per_frame = np.asarray(per_frame)
     out[:, -1] = per_frame
-    raw = np.frombuffer(np.ascontiguousarray(dets).tobytes(), dtype=np.float64).reshape(-1, REC_F64) if len(dets) else np.zeros((0, REC_F64))
-    k0 = 0
-    for f in range(n):
-        c = int(per_frame[f])
-        m = min(c, D_MAX)
-        if m:
-            out[f, : m * REC_F64] = raw[k0 : k0 + m].reshape(-1)
-        k0 += c
+    if len(dets):
+        raw = np.ascontiguousarray(dets).view(np.float64).reshape(-1, REC_F64)
+        start = np.cumsum(per_frame) - per_frame  # first record of every frame
+        for f in np.flatnonzero(per_frame):       # frames with detections are few: no loop over the batch
+            m = min(int(per_frame[f]), D_MAX)
+            out[f, : m * REC_F64] = raw[start[f] : start[f] + m].reshape(-1)
     return out
 
 
