@@ -477,3 +477,17 @@ def test_concurrent_callers_are_serialised(hip):
         seq.process_scan(s.scan, s.tf)
     np.testing.assert_array_equal(dev.read_map(), seq.read_map())
     assert dev.status().detection_its == 6
+
+
+def test_replay_driver_runs_the_three_thread_roles(hip):
+    """examples/vofod_replay: processMsg loop + detached raycast threads + sepclusters timer against one handle (row N3)"""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    subprocess.run(["make", "-C", str(root / "examples")], check=True)
+    out = subprocess.run([str(root / "examples" / "vofod_replay"), "--scans", "30", "--rows", "32", "--cols", "1024", "--voxel", "0.5"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("done: 30 scans") and "detection_its 30" in last, last
+    assert "raycasts 0 " not in last  # the raycast role ran at least once
