@@ -227,6 +227,12 @@ int vofod_load_apriori(vofod_handle* h, const float* xyz, size_t n);
 int vofod_ingest_apriori(vofod_handle* h, const char* filename, const float tf_xyz[3], double yaw_deg, const float sim_correction[3],
                          size_t* n_loaded, size_t* n_voxels);
 
+/* processMsg(sensor_msgs::Range) :581-613 (row N4 of SURVEY 8f): the height range-finder marks the voxel it hits as
+ * background-ish: p = tf * (range, 0, 0); if inLimits(p): map(p) = (map(p) + voxel_map/scores/point) / 2.0.
+ * The reference's validity test `range <= min_range && range >= max_range` is kept as written.
+ * Returns VOFOD_ERR_MAP_RANGE when the point is outside the operation area (map untouched). */
+int vofod_update_ground(vofod_handle* h, float range, float min_range, float max_range, const float tf[12]);
+
 /* test/visualisation access to the three maps (x-fastest, idx = ix + iy*sx + iz*sx*sy: voxel_map.cpp:81) */
 int vofod_read_map(vofod_handle* h, int which, float* dst, size_t n);
 int vofod_write_map(vofod_handle* h, int which, const float* src, size_t n);

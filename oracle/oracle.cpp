@@ -835,6 +835,23 @@ int ORACLE_API(read_map)(vofod_handle* h, int which, float* dst, size_t n)
   return VOFOD_OK;
 }
 
+int ORACLE_API(update_ground)(vofod_handle* h, float range, float min_range, float max_range, const float tf[12])
+{
+  if (!h || !tf)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  if (range <= min_range && range >= max_range)  // :585, as written
+    return VOFOD_OK;
+  // :597  Affine3f * (range, 0, 0): linear * v + translation, the zero terms add nothing
+  const float x = tf[0] * range + tf[3], y = tf[4] * range + tf[7], z = tf[8] * range + tf[11];
+  if (!h->vmap.inLimits(x, y, z))  // :601-605
+    return VOFOD_ERR_MAP_RANGE;
+  const auto ci = h->vmap.coordToIdx(x, y, z);  // VoxelMap::at(x, y, z) = at(coordToIdx(...)) voxel_map.cpp:116-117
+  float& mapval = h->vmap.at(ci[0], ci[1], ci[2]);
+  mapval = static_cast<float>((static_cast<double>(mapval) + h->dp.voxel_map__scores__point) / 2.0);  // :609 (float + double config value)
+  return VOFOD_OK;
+}
+
 int ORACLE_API(write_map)(vofod_handle* h, int which, const float* src, size_t n)
 {
   if (!h || !src)

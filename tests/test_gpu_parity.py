@@ -187,6 +187,23 @@ def test_ingest_apriori_from_file(oracle, hip, tmp_path):
         dev.ingest_apriori(str(tmp_path / "missing.pts"))
 
 
+def test_rangefinder_ground_update_parity(oracle, hip):
+    """row N4: the height range-finder's map update, interleaved with scans, keeps both maps identical"""
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
+    scene = synth.make_scene(9, n_targets=1)
+    rng = np.random.default_rng(2)
+    for k, s in enumerate(synth.scan_sequence(scene, "os1-16", 3, seed0=60)):
+        down = s.tf.copy()
+        down[:, :3] = np.float32([[0, 0, 1], [0, 1, 0], [-1, 0, 0]])  # x axis of the range-finder frame points down
+        for r in rng.uniform(0.5, 60.0, 6):
+            a = ref.update_ground(r, down, allow=(capi.ERR_MAP_RANGE,))
+            b = dev.update_ground(r, down, allow=(capi.ERR_MAP_RANGE,))
+            assert a == b
+        ref.process_scan(s.scan, s.tf)
+        dev.process_scan(s.scan, s.tf)
+        np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+
+
 def test_no_map_update_and_batch_parity(oracle, hip):
     ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=4)
     scene = synth.make_scene(31, n_targets=2)

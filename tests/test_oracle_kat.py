@@ -317,6 +317,29 @@ def test_ingest_apriori_transform_and_centroids(oracle, tmp_path):
     assert np.all(m[~np.isinf(m)] == m[0, 0, 0])
 
 
+def test_rangefinder_ground_update(oracle):
+    # vofod_nodelet.cpp:581-613: p = tf * (range, 0, 0); map(p) = (map(p) + scores/point) / 2.0, outside the area: untouched
+    sp, dp = default_params(oracle)
+    sp.voxel_size = 0.5
+    sp.oparea_offset[:] = (0.0, 0.0, -1.0)  # map spans x,y in [-4,4], z in [-1,3]
+    sp.oparea_size[:] = (8.0, 8.0, 4.0)
+    d = VoFOD(oracle, sp, dp)
+    init = d.read_map()[0, 0, 0]
+    down = np.float32([[0, 0, 1, 1.1], [0, 1, 0, -0.3], [-1, 0, 0, 2.0]])  # the sensor's x axis points down
+    assert d.update_ground(2.6, down) == capi.OK  # hits (1.1, -0.3, -0.6) -> idx (10, 7, 0)
+    m = d.read_map()
+    want = np.float32((np.float64(init) + dp.voxel_map__scores__point) / 2.0)
+    assert m[0, 7, 10] == want and np.count_nonzero(m != init) == 1
+    d.update_ground(2.6, down)
+    assert d.read_map()[0, 7, 10] == np.float32((np.float64(want) + dp.voxel_map__scores__point) / 2.0)
+    before = d.read_map()
+    assert d.update_ground(9.0, down, allow=(capi.ERR_MAP_RANGE,)) == capi.ERR_MAP_RANGE  # z = -7: below the map
+    np.testing.assert_array_equal(d.read_map(), before)
+    # the reference's validity test is `range <= min && range >= max`: a range of 0 with min 0.1 still updates
+    assert d.update_ground(0.0, down, min_range=0.1, max_range=10.0) == capi.OK
+    assert np.count_nonzero(d.read_map() != before) == 1
+
+
 def test_sim_lut_formula(oracle):
     # vofod_nodelet.cpp:374-420: yaw = col*2pi/(w-1), pitch = row*vfov/(h-1) - vfov/2
     lut = sim_lut(oracle, 1024, 128, math.radians(45.0)).reshape(128, 1024, 3)

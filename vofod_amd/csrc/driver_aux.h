@@ -720,6 +720,30 @@ int vofod_read_map(vofod_handle* h, int which, float* dst, size_t n)
   return VOFOD_OK;
 }
 
+int vofod_update_ground(vofod_handle* h, float range, float min_range, float max_range, const float tf[12])
+{
+  if (!h || !tf)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  if (range <= min_range && range >= max_range)  // vofod_nodelet.cpp:585, as written
+    return VOFOD_OK;
+  // one voxel at the range-finder's rate: read, blend on the host in the reference's double expression, write back
+  const float p[3] = {tf[0] * range + tf[3], tf[4] * range + tf[7], tf[8] * range + tf[11]};  // :597
+  int idx[3];
+  h->hg.coordToIdx(p, idx);
+  if (!h->hg.inLimits(idx))  // :601-605
+    return VOFOD_ERR_MAP_RANGE;
+  float* cell = h->d_map + h->hg.lin(idx);
+  float m = 0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(&m, cell, sizeof(float), hipMemcpyDeviceToHost));
+  m = static_cast<float>((static_cast<double>(m) + h->dp.voxel_map__scores__point) / 2.0);  // :609
+  HIPCHK(hipMemcpy(cell, &m, sizeof(float), hipMemcpyHostToDevice));
+  h->mapbits_valid = false;
+  return VOFOD_OK;
+}
+
 int vofod_write_map(vofod_handle* h, int which, const float* src, size_t n)
 {
   if (!h || !src)

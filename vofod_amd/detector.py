@@ -134,6 +134,14 @@ class VoFOD:
         self._check(self.lib.ingest_apriori(self.h, filename.encode(), capi.ptr(t), float(yaw_deg), capi.ptr(c), C.byref(nl), C.byref(nv)), "vofod_ingest_apriori")
         return nl.value, nv.value
 
+    def update_ground(self, range_m: float, tf, min_range: float = 0.0, max_range: float = 100.0, allow=()):
+        """height range-finder message (vofod_nodelet.cpp:581-613); returns the status (MAP_RANGE may be allowed)"""
+        t = np.ascontiguousarray(tf, dtype=np.float32).reshape(12)
+        st = self.lib.update_ground(self.h, float(range_m), float(min_range), float(max_range), capi.ptr(t))
+        if st != capi.OK and st not in allow:
+            self._check(st, "vofod_update_ground")
+        return st
+
     def read_map(self, which: int = capi.MAP_VOXELS) -> np.ndarray:
         """Returns the map as [sz, sy, sx] (x fastest: voxel_map.cpp:81)."""
         out = np.empty(self.n_voxels, dtype=np.float32)
