@@ -319,6 +319,17 @@ int vofod_load_cloud(const char* filename, float* xyz, size_t cap, size_t* n_out
 /* simulated sensor LUT of initialize_sensor_lut_simulation (vofod_nodelet.cpp:374-420) */
 int vofod_sim_lut(int32_t w, int32_t h, float vfov, float* directions /* 3*w*h */);
 
+/* initialize_sensor_lut (vofod_nodelet.cpp:358-372) from the Ouster metadata (row N1 of SURVEY 8f): [3P] ouster::make_xyz_lut
+ * restated, then cast to float and directions normalised.  tf16 = lidar_to_sensor_transform, row-major 4x4, NULL = identity;
+ * azimuth / altitude: beam angles in degrees, one per row.  Output layout as vofod_static_params::lut_*. */
+int vofod_ouster_lut(int32_t w, int32_t h, double range_unit, double lidar_origin_to_beam_origin_mm, const double* tf16,
+                     const double* azimuth_deg, const double* altitude_deg, float* directions /* 3*w*h */, float* offsets /* 3*w*h */);
+
+/* load_mask (:506-560) after the image is decoded: plain copy or "mangling" into the packets' staggered column-major order
+ * (:527-541, pixel_shift_by_row from the metadata, NULL = zeros); image NULL = no usable file -> all ones (:558). */
+int vofod_mask_layout(const uint8_t* image /* w*h, row-major */, int32_t w, int32_t h, const int32_t* pixel_shift_by_row /* h */,
+                      int32_t mangle, uint8_t* mask /* w*h */);
+
 /* ------------------------------------------------------------ diagnostics */
 
 /* Per-kernel device time, measured with HIP events on the handle's own stream (the reference analogue is

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from vofod_amd import capi
-from vofod_amd.detector import ScanData, VoFOD, default_params, load_cloud, sim_lut, voxel_grid_counted, voxel_grid_weighted, cluster
+from vofod_amd.detector import ScanData, VoFOD, default_params, load_cloud, mask_layout, ouster_lut, sim_lut, voxel_grid_counted, voxel_grid_weighted, cluster
 
 
 def _pts(*xyz):
@@ -338,6 +338,35 @@ def test_rangefinder_ground_update(oracle):
     # the reference's validity test is `range <= min && range >= max`: a range of 0 with min 0.1 still updates
     assert d.update_ground(0.0, down, min_range=0.1, max_range=10.0) == capi.OK
     assert np.count_nonzero(d.read_map() != before) == 1
+
+
+def test_ouster_lut_and_mask_layout(oracle):
+    # vofod_nodelet.cpp:358-372 + [3P] make_xyz_lut: pixel (u, v): encoder = 2 pi - v 2 pi / w, azimuth = -az[u], altitude = alt[u]
+    w, h = 4, 2
+    d, o = ouster_lut(oracle, w, h, azimuth_deg=[0.0, 90.0], altitude_deg=[0.0, 30.0], origin_mm=15.0)
+    d, o = d.reshape(h, w, 3), o.reshape(h, w, 3)
+    # row 0 (no beam offsets): unit vectors turning clockwise with the column, offsets (cos e, sin e, 0) - dir = 0
+    np.testing.assert_allclose(d[0], [[1, 0, 0], [0, -1, 0], [-1, 0, 0], [0, 1, 0]], atol=1e-6)
+    np.testing.assert_allclose(o[0], 0, atol=1e-9)
+    # row 1: azimuth -90 deg, altitude 30 deg: column 0 looks along -y, tilted up; normalised in float (:369)
+    c30, s30 = math.cos(math.radians(30)), math.sin(math.radians(30))
+    np.testing.assert_allclose(d[1, 0], [0, -c30, s30], atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(d.reshape(-1, 3), axis=1), 1.0, atol=1e-6)
+    # offset = ((cos e, sin e, 0) - dir) * 15 mm * 0.001 (range_unit): encoder 2 pi -> (1, 0, 0) - (0, -c30, s30)
+    np.testing.assert_allclose(o[1, 0], np.array([1.0, c30, -s30]) * 0.015, atol=1e-7)
+    # lidar_to_sensor transform: rotation by 180 deg about z + 36.18 mm up (the usual Ouster metadata): directions flip in x,y
+    tf = np.diag([-1.0, -1.0, 1.0, 1.0])
+    tf[2, 3] = 36.18
+    d2, o2 = ouster_lut(oracle, w, h, [0.0, 90.0], [0.0, 30.0], origin_mm=15.0, tf=tf)
+    np.testing.assert_allclose(d2.reshape(h, w, 3)[0, 0], [-1, 0, 0], atol=1e-6)
+    np.testing.assert_allclose(o2.reshape(h, w, 3)[0, 0], [0, 0, 0.03618], atol=1e-7)
+    # load_mask :527-541: mask[((v + shift[u]) % w) * h + u] = image[u * w + v]; no image: all ones (:558)
+    img = np.arange(1, 9, dtype=np.uint8).reshape(h, w)  # rows [1 2 3 4], [5 6 7 8]
+    m = mask_layout(oracle, img, w, h, pixel_shift_by_row=[0, 1], mangle=True)
+    #   column-major pairs (u=0, u=1) per shifted column vv: vv=0: (1, 8)  vv=1: (2, 5)  vv=2: (3, 6)  vv=3: (4, 7)
+    assert m.tolist() == [1, 8, 2, 5, 3, 6, 4, 7]
+    assert mask_layout(oracle, img, w, h, mangle=False).tolist() == list(range(1, 9))
+    assert mask_layout(oracle, None, w, h).tolist() == [1] * 8
 
 
 def test_sim_lut_formula(oracle):

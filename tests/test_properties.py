@@ -2,6 +2,7 @@
 import ctypes as C
 
 import numpy as np
+import pytest
 from hypothesis import given, settings, strategies as st
 
 from vofod_amd import capi
@@ -53,3 +54,29 @@ def test_cluster_labels_match_bruteforce_union_find(oracle, seed, n, tol):
     # labels are canonical: the smallest member of each component
     for l in np.unique(labels):
         assert np.flatnonzero(labels == l)[0] == l
+
+
+def test_sensor_helpers_of_the_product_match_the_oracle(oracle):
+    """vofod_ouster_lut / vofod_mask_layout are host code on both sides (no GPU involved): identical outputs"""
+    import vofod_amd
+    from vofod_amd.detector import mask_layout, ouster_lut
+
+    try:
+        hip = vofod_amd.library()
+    except (ImportError, OSError) as e:  # libamdhip64 missing on a CPU-only box
+        pytest.skip(f"product library not loadable here: {e}")
+    rng = np.random.default_rng(11)
+    w, h = 64, 16
+    az = rng.uniform(-3, 3, h)
+    alt = np.linspace(16.6, -16.6, h)
+    tf = np.eye(4)
+    tf[:3, :3] = [[-1, 0, 0], [0, -1, 0], [0, 0, 1]]
+    tf[:3, 3] = [0.0, 0.0, 36.18]
+    for kw in ({}, {"tf": tf, "origin_mm": 15.806}):
+        a = ouster_lut(oracle, w, h, az, alt, **kw)
+        b = ouster_lut(hip, w, h, az, alt, **kw)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    sh = rng.integers(0, 9, h).astype(np.int32)
+    np.testing.assert_array_equal(mask_layout(oracle, img, w, h, sh), mask_layout(hip, img, w, h, sh))

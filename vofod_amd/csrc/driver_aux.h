@@ -461,6 +461,88 @@ int vofod_sim_lut(int32_t w, int32_t hh, float vfov, float* directions)
   return VOFOD_OK;
 }
 
+
+// initialize_sensor_lut (vofod_nodelet.cpp:358-372).  [3P] ouster::make_xyz_lut restated from the published ouster_client
+// sources (ouster_example 2.x lidar_scan.cpp; the reference pins no version): per pixel i = u*w + v
+//   encoder = 2 pi - v * 2 pi / w,  azimuth = -az[u] deg,  altitude = alt[u] deg
+//   direction = (cos(enc + az) cos(alt), sin(enc + az) cos(alt), sin(alt))
+//   offset    = ((cos(enc), sin(enc), 0) - direction) * lidar_origin_to_beam_origin_mm
+//   both rotated by the lidar_to_sensor transform (offset also translated), both scaled by range_unit;
+// then the nodelet casts to float and normalises the directions column by column (:368-369).
+int vofod_ouster_lut(int32_t w, int32_t hh, double range_unit, double lidar_origin_to_beam_origin_mm, const double* tf16, const double* azimuth_deg, const double* altitude_deg,
+                       float* directions, float* offsets)
+{
+  if (w < 1 || hh < 1 || !azimuth_deg || !altitude_deg || !directions || !offsets)
+    return VOFOD_ERR_INVALID_ARG;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0};
+  if (tf16)
+    for (int r = 0; r < 3; r++)
+    {
+      for (int c = 0; c < 3; c++)
+        R[3 * r + c] = tf16[4 * r + c];
+      T[r] = tf16[4 * r + 3];
+    }
+  const double azimuth_radians = M_PI * 2.0 / w;
+  for (int u = 0; u < hh; u++)
+    for (int v = 0; v < w; v++)
+    {
+      const size_t i = static_cast<size_t>(u) * w + v;
+      const double encoder = 2.0 * M_PI - (v * azimuth_radians);
+      const double azimuth = -azimuth_deg[u] * M_PI / 180.0;
+      const double altitude = altitude_deg[u] * M_PI / 180.0;
+      double d[3] = {std::cos(encoder + azimuth) * std::cos(altitude), std::sin(encoder + azimuth) * std::cos(altitude), std::sin(altitude)};
+      double o[3] = {std::cos(encoder) - d[0], std::sin(encoder) - d[1], -d[2]};
+      for (int c = 0; c < 3; c++)
+        o[c] *= lidar_origin_to_beam_origin_mm;
+      // row vector times rot = transform.topLeftCorner(3,3).transpose(): element j = (d0*R[j][0] + d1*R[j][1]) + d2*R[j][2]
+      double dr[3], orr[3];
+      for (int j = 0; j < 3; j++)
+      {
+        dr[j] = (d[0] * R[3 * j] + d[1] * R[3 * j + 1]) + d[2] * R[3 * j + 2];
+        orr[j] = ((o[0] * R[3 * j] + o[1] * R[3 * j + 1]) + o[2] * R[3 * j + 2]) + T[j];
+      }
+      float df[3];
+      for (int j = 0; j < 3; j++)
+      {
+        df[j] = static_cast<float>(dr[j] * range_unit);
+        offsets[3 * i + j] = static_cast<float>(orr[j] * range_unit);
+      }
+      const float norm = std::sqrt((df[0] * df[0] + df[1] * df[1]) + df[2] * df[2]);  // colwise().normalize() :369
+      for (int j = 0; j < 3; j++)
+        directions[3 * i + j] = df[j] / norm;
+    }
+  return VOFOD_OK;
+}
+
+// load_mask (vofod_nodelet.cpp:506-560) after cv::imread: the image (row-major, w x h, or NULL when the file is missing or
+// has the wrong size) is copied as is, or "mangled" (:527-541) into the staggered column-major order of the raw Ouster
+// packets, index ((v + pixel_shift_by_row[u]) % w) * h + u; entries no image provides are 1 (:558).
+int vofod_mask_layout(const uint8_t* image, int32_t w, int32_t hh, const int32_t* pixel_shift_by_row, int32_t mangle, uint8_t* mask)
+{
+  if (w < 1 || hh < 1 || !mask)
+    return VOFOD_ERR_INVALID_ARG;
+  const size_t n = static_cast<size_t>(w) * hh;
+  if (!image)
+  {
+    std::fill(mask, mask + n, static_cast<uint8_t>(1));
+    return VOFOD_OK;
+  }
+  if (!mangle)
+  {
+    std::copy(image, image + n, mask);
+    return VOFOD_OK;
+  }
+  std::fill(mask, mask + n, static_cast<uint8_t>(0));  // std::vector::resize value-initialises (:519); every slot is written below
+  for (int u = 0; u < hh; u++)
+    for (int v = 0; v < w; v++)
+    {
+      const int shift = pixel_shift_by_row ? pixel_shift_by_row[u] : 0;
+      const size_t vv = static_cast<size_t>(v + shift) % static_cast<size_t>(w);
+      mask[vv * hh + u] = image[static_cast<size_t>(u) * w + v];
+    }
+  return VOFOD_OK;
+}
+
 void vofod_destroy(vofod_handle* h)
 {
   if (!h)

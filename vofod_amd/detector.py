@@ -331,3 +331,27 @@ def sim_lut(lib, w: int, h: int, vfov: float) -> np.ndarray:
     if st != capi.OK:
         raise VofodError(st, "vofod_sim_lut")
     return out
+
+
+def ouster_lut(lib, w: int, h: int, azimuth_deg, altitude_deg, range_unit: float = 0.001, origin_mm: float = 0.0, tf=None):
+    """initialize_sensor_lut (vofod_nodelet.cpp:358-372): (directions, offsets), each [h*w, 3] float32"""
+    az = np.ascontiguousarray(azimuth_deg, dtype=np.float64)
+    alt = np.ascontiguousarray(altitude_deg, dtype=np.float64)
+    t = None if tf is None else np.ascontiguousarray(tf, dtype=np.float64).reshape(16)
+    d = np.zeros((h * w, 3), dtype=np.float32)
+    o = np.zeros((h * w, 3), dtype=np.float32)
+    st = lib.ouster_lut(w, h, float(range_unit), float(origin_mm), None if t is None else capi.ptr(t), capi.ptr(az), capi.ptr(alt), capi.ptr(d), capi.ptr(o))
+    if st != capi.OK:
+        raise RuntimeError(f"vofod_ouster_lut: status {st}")
+    return d, o
+
+
+def mask_layout(lib, image, w: int, h: int, pixel_shift_by_row=None, mangle: bool = True):
+    """load_mask (vofod_nodelet.cpp:506-560) after decoding: uint8[w*h]"""
+    img = None if image is None else np.ascontiguousarray(image, dtype=np.uint8).reshape(h * w)
+    sh = None if pixel_shift_by_row is None else np.ascontiguousarray(pixel_shift_by_row, dtype=np.int32)
+    out = np.zeros(h * w, dtype=np.uint8)
+    st = lib.mask_layout(None if img is None else capi.ptr(img), w, h, None if sh is None else capi.ptr(sh), int(bool(mangle)), capi.ptr(out))
+    if st != capi.OK:
+        raise RuntimeError(f"vofod_mask_layout: status {st}")
+    return out
