@@ -193,7 +193,7 @@ def main():
                 "map_voxels": det.n_voxels,
                 "map_warm_scans": args.map_warm_scans,
                 "detections_per_step": n_det / args.steps,
-                "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight on separate streams",
+                "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight (own streams below 200 frames per batch, one stream above: the kernels then fill the chip)",
             },
         }
         # single-stream (stateful, sequential) latency of the same scan shape

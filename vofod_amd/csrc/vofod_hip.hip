@@ -1329,8 +1329,11 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     }
     ~ChainStream() { h->stream = saved; }
   };
-  // VOFOD_TWO_CHAINS=0 keeps every in-flight batch on one stream (measured 19 % slower: the kernels are latency bound)
-  static const bool two_chains = !(std::getenv("VOFOD_TWO_CHAINS") && std::atoi(std::getenv("VOFOD_TWO_CHAINS")) == 0);
+  // In-flight batches on streams of their own overlap their kernel chains: a gain while a batch leaves CUs idle (32 / 64 /
+  // 128 frames: +31 / +56 / +16 %), a loss once one batch's kernels fill the chip (256 frames: -6 %, co-running chains only
+  // slow each other down).  VOFOD_TWO_CHAINS=0 / 1 forces one or the other.
+  static const int two_chains_env = std::getenv("VOFOD_TWO_CHAINS") ? std::atoi(std::getenv("VOFOD_TWO_CHAINS")) : -1;
+  const bool two_chains = two_chains_env >= 0 ? two_chains_env != 0 : n < 200;
   hipStream_t my_stream = nullptr;
   if (two_chains && phase == FRAMES_LAUNCH)
     for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
