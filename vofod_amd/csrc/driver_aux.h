@@ -555,7 +555,7 @@ void vofod_destroy(vofod_handle* h)
     w.release();
   h->aux.release();
   h->sepws.release();
-  void* ptrs[] = {h->d_map, h->d_flags, h->d_ray, h->d_mapbits, h->d_mapclose, h->d_counter, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_rows, h->d_crows, h->d_boxstage, h->d_idxstage,
+  void* ptrs[] = {h->d_map, h->d_flags, h->d_ray, h->d_mapbits, h->d_mapclose, h->d_prof_slab, h->d_prof_ccl, h->d_counter, h->d_lut_dirs, h->d_lut_offs, h->d_mask, h->d_rows, h->d_crows, h->d_boxstage, h->d_idxstage,
                   h->sep.d_tbits, h->sep.d_tpop, h->sep.d_tprefix, h->sep.d_bsum, h->sep.d_px, h->sep.d_py, h->sep.d_pz, h->sep.d_pi, h->sep.d_sure, h->sep.d_sure_pre,
                   h->sep.d_vcnt, h->sep.d_first, h->sep.d_nsure, h->sep.d_offsets, h->sep.d_small};
   for (void* p : ptrs)

@@ -293,6 +293,7 @@ struct HostCluster
 
 struct vofod_handle
 {
+  unsigned long long *d_prof_slab = nullptr, *d_prof_ccl = nullptr;  // stamp buffers of the VOFOD_LDS_PROF diagnostics
   bool lds_ccl_off = false;  // a frame overflowed the LDS clustering kernel once: stay on the global-memory kernels
   std::mutex mtx;
   vofod_static_params sp{};
@@ -820,7 +821,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     // VOFOD_SLAB_EMIT=0 keeps the separate emission kernels for every batch size
     static const bool slab_emit_on = !(std::getenv("VOFOD_SLAB_EMIT") && std::atoi(std::getenv("VOFOD_SLAB_EMIT")) == 0);
     ws.bitmap_clean = false;
-    static unsigned long long* d_prof_se = nullptr;
+    unsigned long long*& d_prof_se = h->d_prof_slab;  // VOFOD_LDS_PROF=1 (diagnostics): per-handle stamp buffer
     if (!d_prof_se && std::getenv("VOFOD_LDS_PROF"))
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof_se), sizeof(unsigned long long) * 16 * 4096));
     if (slab_emit_on && n >= 128)
@@ -1026,7 +1027,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     {
       (void)allow_lds;
       ws.lean_emit = false;
-      static unsigned long long* d_prof = nullptr;
+      unsigned long long*& d_prof = h->d_prof_ccl;
       if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 16 * 4096));
       KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table),
