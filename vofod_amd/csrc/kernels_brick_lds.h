@@ -26,7 +26,10 @@ namespace vk
 
 constexpr int LB_MAX = 7168;          // occupied bricks per frame
 constexpr int LB_BITWORDS = 9984;     // 32-bit words of the brick-lattice bitmap: 319 488 bricks = 20 M cells
-constexpr int LB_THREADS = 1024;
+#ifndef VOFOD_LB_THREADS
+#define VOFOD_LB_THREADS 1024  /* 512 (an experiment: half the waves per CU) makes the kernel this much slower: see DESIGN 5.3 */
+#endif
+constexpr int LB_THREADS = VOFOD_LB_THREADS;
 constexpr int LB_LANES = 8;           // lanes sharing one brick in phase D
 constexpr int LB_MAX_ROWS = 16;       // (dy,dz) rows of the half stencil (13 for a reach of 2 bricks)
 constexpr int LB_MAX_OFF = 64;
