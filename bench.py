@@ -124,10 +124,13 @@ def main():
     # all-gather payload: D_MAX 128-byte detection records + the count per frame, RCCL over xGMI
     rec_local = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
     rec_all = torch.zeros((world, F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
-    rec_host = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64).pin_memory()
+    rec_hosts = [torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64).pin_memory() for _ in range(2)]  # the async copy of one step is not overwritten by the next
+    pub_count = [0]
 
     def publish(dets, per):
         if world > 1:
+            rec_host = rec_hosts[pub_count[0] & 1]
+            pub_count[0] += 1
             vdist.pack_detections(dets, per, out=rec_host.numpy())
             rec_local.copy_(rec_host, non_blocking=True)
             vdist.allgather_detections(rec_local, rec_all)
