@@ -44,6 +44,7 @@ struct FrameHdr
   uint32_t n_cand;  // voxels of candidate (far, small) clusters appended to the member list
   uint32_t need_words;  // bitmap words the lattice needs (reported even when it exceeds the workspace)
   uint32_t n_bricks;    // occupied 4x4x4 bricks (brick-level clustering)
+  uint32_t n_undecided; // voxels whose own map row is empty: k_closefar_sweep tests their whole stencil
 };
 
 // Parameters constant over a call (passed by value).

@@ -514,7 +514,8 @@ __global__ __launch_bounds__(256) void k_dilate(const MapGeom mg, const ClosePar
 
 __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows,
                                                   const FrameHdr* hdrs, const unsigned long long* __restrict__ mapbits, VoxelArrays va_all,
-                                                  const uint32_t* labels_all, const unsigned long long* __restrict__ mapclose)
+                                                  const uint32_t* labels_all, const unsigned long long* __restrict__ mapclose, CandMember* __restrict__ undecided_all,
+                                                  FrameHdr* hdrs_w)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
@@ -568,8 +569,29 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
     if (run_heads(hit_root, lane, end) && hit_root != 0xffffffffu)
       __hip_atomic_store(&va.cclose[hit_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // Phase B: four undecided voxels at a time, 16 lanes each sweeping the stencil rows
+  // Phase B.  With a list (single frames: the launch has too few waves to hide the sweep's latency) the undecided voxels
+  // are handed to k_closefar_sweep, one reservation per wave; otherwise they are swept here.
   unsigned long long todo = __ballot(undecided);
+  if (undecided_all)
+  {
+    if (todo)
+    {
+      const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+      uint32_t base = 0;
+      if (lane == leader)
+        base = atomicAdd(&hdrs_w[FRAME].n_undecided, static_cast<uint32_t>(__popcll(todo)));
+      base = __shfl(base, leader);
+      if (undecided)
+      {
+        CandMember cm;
+        cm.root = root;
+        cm.v = v;
+        undecided_all[static_cast<size_t>(FRAME) * g.vox_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = cm;
+      }
+    }
+    return;
+  }
+  // four undecided voxels at a time, 16 lanes each sweeping the stencil rows
   const int grp = lane >> 4, sub = lane & 15;
   while (todo)
   {
@@ -609,6 +631,55 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
     if (found && sub == 0)
       __hip_atomic_store(&va.cclose[r_root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// The stencil sweep of the voxels k_closefar could not decide from their own row: 16 lanes per voxel over the nearest-first
+// rows, as many workgroups as the list needs (a kernel of its own so that a single frame gets thousands of waves).
+__global__ __launch_bounds__(256) void k_closefar_sweep(const GridParams g, const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows, const FrameHdr* hdrs,
+                                                        const unsigned long long* __restrict__ mapbits, VoxelArrays va_all, const CandMember* __restrict__ undecided_all)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const uint32_t n = hdrs[FRAME].n_undecided;
+  const uint32_t u = (BX * blockDim.x + threadIdx.x) >> 4;
+  if ((BX * blockDim.x >> 4) >= n)
+    return;
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & 15;
+  const bool live = u < n;
+  uint32_t root = 0;
+  int ox = 0, oy = 0, oz = 0;
+  bool done = !live;
+  if (live)
+  {
+    const CandMember cm = undecided_all[static_cast<size_t>(FRAME) * g.vox_cap + u];
+    root = cm.root;
+    const float4 p = va.pts[cm.v];
+    ox = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.x, mg.off[0]), mg.vs_inv)));
+    oy = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.y, mg.off[1]), mg.vs_inv)));
+    oz = static_cast<int>(floorf(__fmul_rn(__fsub_rn(p.z, mg.off[2]), mg.vs_inv)));
+    done = __hip_atomic_load(&va.cclose[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // the cluster is close already
+  }
+  const unsigned long long gmask = 0xffffull << (grp * 16);
+  bool found = false;
+  for (int r0 = 1; r0 < cp.n_rows; r0 += 16)  // row 0 was tested by k_closefar
+  {
+    bool hit = false;
+    const int r = r0 + sub;
+    if (!done && r < cp.n_rows)
+      hit = close_row_hit(mg, mapbits, rows[r], ox, oy, oz);
+    if (__ballot(hit) & gmask)
+    {
+      done = true;
+      found = true;
+    }
+    if (!__ballot(!done))
+      break;
+  }
+  if (found && sub == 0)
+    __hip_atomic_store(&va.cclose[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // K10 + cluster table + candidate members.

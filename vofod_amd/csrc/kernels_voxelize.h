@@ -106,6 +106,7 @@ __global__ void k_init_hdr(FrameHdr* hdrs)
     h.V = h.C = h.n_cand = 0;
     h.need_words = 0;
     h.n_bricks = 0;
+    h.n_undecided = 0;
   }
 }
 

@@ -1432,7 +1432,15 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // ---- K8/K9 findCloseFarClusters :703-750 (tables and images were prepared before the chain was enqueued)
   const uint32_t gv = (ws.vox_cap + 255u) / 256u;
   if (!ws.closefar_fused)
-    KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels, use_dilated ? h->d_mapclose : nullptr);
+  {
+    // few frames: the undecided voxels go through a list to a sweep kernel with 16 lanes per voxel (ws.d_cand is free until
+    // k_finalize); many frames: swept in place
+    const bool split = n < 8 && !use_dilated;
+    KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_labels, use_dilated ? h->d_mapclose : nullptr,
+            split ? ws.d_cand : nullptr, ws.d_hdrs);
+    if (split)
+      KLAUNCH(h, k_closefar_sweep, fgrid(g, (ws.vox_cap * 16u + 255u) / 256u), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_cand);
+  }
   ws.closefar_fused = false;
   if (dbg)
     HIPCHK(hipEventRecord(ev[3], h->stream));
