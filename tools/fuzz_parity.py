@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle parity sweep (runs on the GPU box; test infrastructure, not part of the suites).
+
+Every iteration draws a scene, a sensor, a voxel size, a clustering tolerance and a batch size, warms both maps with a
+few sequential scans (map update, raycast and sepclusters roles) and compares a read-only batch frame by frame
+(weighted cloud, labels, cluster table, detections) plus the maps.  Stops at the first mismatch with the seed.
+
+    python tools/fuzz_parity.py --seconds 400 --seed 1
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    import vofod_amd
+    from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair
+    from vofod_amd import capi, synth
+    from vofod_amd.detector import VofodError
+
+    hip = vofod_amd.library()
+    oracle = capi.Library(ROOT / "oracle" / "libvofod_oracle.so", "vofod_oracle_")
+    t_end = time.time() + args.seconds
+    it = n_bail = 0
+    while time.time() < t_end:
+        seed = args.seed * 100000 + it
+        rng = np.random.default_rng(seed)
+        sensor = rng.choice(["os1-16", "os1-16", "os1-128"])
+        voxel = float(rng.choice([0.25, 0.25, 0.5]))  # sizes that tile the operation area (others make the reference throw: MAP_RANGE)
+        tol = float(rng.choice([1.0, 1.5, 1.5, 2.0]))
+        n_batch = int(rng.choice([4, 6, 17, 130])) if sensor == "os1-16" else int(rng.choice([4, 6]))
+        n_warm = int(rng.integers(0, 5))
+        use_apriori = bool(rng.integers(0, 2))
+        desc = f"seed {seed}: {sensor} voxel {voxel} tol {tol} batch {n_batch} warm {n_warm} apriori {use_apriori}"
+        try:
+            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch, ground_points_max_distance=tol)
+            scene = synth.make_scene(int(rng.integers(0, 10_000)), n_targets=int(rng.integers(0, 4)))
+            if use_apriori:
+                ap_pts = synth.apriori_points(scene, voxel)
+                for d in (ref, dev):
+                    d.load_apriori(ap_pts)
+            else:
+                for d in (ref, dev):
+                    synth.seed_ground(d)
+            def status_of(fn):
+                try:
+                    fn()
+                    return capi.OK
+                except VofodError as e:
+                    return e.status
+
+            bailed = False
+            for k, s in enumerate(synth.scan_sequence(scene, sensor, n_warm, seed0=int(rng.integers(0, 10_000)))):
+                sa = status_of(lambda: ref.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST))
+                sb = status_of(lambda: dev.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST))
+                assert sa == sb, f"status {sa} (oracle) vs {sb} (HIP)"
+                if sa != capi.OK:  # e.g. MAP_RANGE: a voxel size that does not tile the operation area (the reference would throw)
+                    bailed = True
+                    break
+                for d in (ref, dev):
+                    if k % 2 == 1:
+                        st, sure = d.sepclusters_begin(allow=(capi.ERR_EMPTY,))
+                        if st == capi.OK and sure:
+                            d.sepclusters_finish()
+            if bailed:
+                it += 1
+                n_bail += 1
+                continue
+            for d in (ref, dev):
+                if d.status().raycast_pending:
+                    d.raycast_finish(allow=(capi.ERR_RAYCAST_NO_DETECTION, capi.ERR_RAYCAST_EMPTY))
+            # the raycast accumulator is a float-atomic sum on the device: bring both to the oracle's map before comparing bits
+            for which in (capi.MAP_VOXELS, capi.MAP_FLAGS):
+                dev.write_map(which, ref.read_map(which))
+            base = synth.scan_sequence(scene, sensor, min(n_batch, 9), seed0=int(rng.integers(0, 10_000)))
+            scans = [base[i % len(base)] for i in range(n_batch)]
+            tfs = np.stack([s.tf for s in scans])
+            da, pa, ga = ref.process_batch([s.scan for s in scans], tfs, debug=True)
+            db, pb, gb = dev.process_batch([s.scan for s in scans], tfs, debug=True)
+            np.testing.assert_array_equal(pb, pa)
+            assert_detections_equal(da, db)
+            for x, y in zip(ga, gb):
+                assert_scan_debug_equal(x, y)
+            # one sequential scan with map update on top
+            s = base[0]
+            ra, ha = ref.process_scan(s.scan, s.tf, debug=True)
+            rb, hb = dev.process_scan(s.scan, s.tf, debug=True)
+            assert_scan_debug_equal(ha, hb)
+            assert_detections_equal(ra, rb)
+            np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+        except Exception as e:  # noqa: BLE001
+            print(f"MISMATCH at {desc}\n{type(e).__name__}: {str(e)[:1500]}", flush=True)
+            return 1
+        it += 1
+        if it % 5 == 0:
+            print(f"{it} iterations ok, last: {desc}", flush=True)
+    print(f"fuzz ok: {it} iterations in {args.seconds:.0f} s ({n_bail} ended early with equal error statuses)", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
