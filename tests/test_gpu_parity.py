@@ -315,6 +315,38 @@ def test_batches_of_dense_and_empty_frames(oracle, hip, n_frames):
         assert ga[1]["n_input_after_crop"] - len(ga[1]["weighted"]) > 50_000  # extras far beyond the LDS staging area
 
 
+def test_error_statuses_of_unusual_voxel_sizes_match(oracle, hip):
+    """found by tools/fuzz_parity.py: a voxel size that does not tile the operation area puts weighted points outside the
+    map (the reference's vector::at would throw: MAP_RANGE); 1.0 m voxels make sepclusters' parameters invalid.  Both
+    implementations must report the same status, scan by scan."""
+    from vofod_amd.detector import VofodError
+
+    def status_of(fn):
+        try:
+            fn()
+            return capi.OK
+        except VofodError as e:
+            return e.status
+
+    scene = synth.make_scene(5, n_targets=2)
+    for voxel in (0.3, 1.0):
+        ref, dev = make_pair(oracle, hip, "os1-16", voxel, ground_points_max_distance=1.5)
+        ap = synth.apriori_points(scene, voxel)
+        for d in (ref, dev):
+            d.load_apriori(ap)
+        seen = set()
+        for k, s in enumerate(synth.scan_sequence(scene, "os1-16", 4, seed0=3)):
+            a = status_of(lambda: ref.process_scan(s.scan, s.tf))
+            b = status_of(lambda: dev.process_scan(s.scan, s.tf))
+            assert a == b, (voxel, k, a, b)
+            seen.add(a)
+            a = status_of(lambda: ref.sepclusters_begin(allow=(capi.ERR_EMPTY,)))
+            b = status_of(lambda: dev.sepclusters_begin(allow=(capi.ERR_EMPTY,)))
+            assert a == b, (voxel, k, "sepclusters", a, b)
+            seen.add(a)
+        assert seen - {capi.OK}, f"voxel {voxel}: expected at least one error status, saw {seen}"
+
+
 def test_error_paths(oracle, hip):
     ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
     scene = synth.make_scene(1)
