@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dyn", action="store_true", help="also randomise dynamic (detection_params.yaml) parameters")
     args = ap.parse_args()
     import vofod_amd
     from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair
@@ -44,7 +45,16 @@ def main():
         use_apriori = bool(rng.integers(0, 2))
         desc = f"seed {seed}: {sensor} voxel {voxel} tol {tol} batch {n_batch} warm {n_warm} apriori {use_apriori}"
         try:
-            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch, ground_points_max_distance=tol)
+            dyn = {"ground_points_max_distance": tol}
+            if args.dyn:  # classification / explore / threshold parameters off their defaults
+                dyn["classification__min_points"] = int(rng.choice([1, 2, 3, 5]))
+                dyn["classification__max_size"] = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
+                dyn["classification__max_explore_distance"] = float(rng.choice([3.0, 6.0, 10.0]))
+                dyn["classification__max_distance"] = float(rng.choice([10.0, 20.0, 40.0]))
+                dyn["voxel_map__thresholds__frontiers"] = float(rng.choice([-700.0, -500.0, -300.0]))
+                dyn["raycast__new_update_rule"] = int(rng.integers(0, 2))
+                desc += f" dyn {dyn}"
+            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch, **dyn)
             scene = synth.make_scene(int(rng.integers(0, 10_000)), n_targets=int(rng.integers(0, 4)))
             if use_apriori:
                 ap_pts = synth.apriori_points(scene, voxel)
