@@ -56,22 +56,6 @@ def build_detector(lib, sensor, voxel_size, frames, device):
     return VoFOD(lib, sp, dp)
 
 
-def warm_map(det, scene, sensor, n_scans, seed0):
-    """config 2 of SURVEY 8d: map pre-warmed by n scans with the raycast and sepclusters roles interleaved."""
-    from vofod_amd import capi, synth
-
-    synth.seed_ground(det)
-    scans = synth.scan_sequence(scene, sensor, n_scans, seed0=seed0)
-    for k, s in enumerate(scans):
-        det.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
-        if k % 2 == 1:
-            st, sure = det.sepclusters_begin(allow=(capi.ERR_EMPTY,))
-            if st == capi.OK and sure:
-                det.sepclusters_finish()
-    if det.status().raycast_pending:
-        det.raycast_finish(allow=(capi.ERR_RAYCAST_NO_DETECTION, capi.ERR_RAYCAST_EMPTY))
-
-
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -100,13 +84,13 @@ def main():
     lib = vofod_amd.library()
     F = args.frames
     det = build_detector(lib, args.sensor, args.voxel_size, F, local_rank)
-    scene = synth.make_scene(0, n_targets=3)
-    warm_map(det, scene, args.sensor, args.map_warm_scans, seed0=1000)
+    scene = synth.bench_scene()
+    synth.warm_map(det, scene, args.sensor, args.map_warm_scans)
 
     # F independent frames per rank (seeds differ per rank), resident in HBM as packed SoA columns
     h, w, _, _ = synth.SENSORS[args.sensor]
     n_pts = h * w
-    host_scans = [synth.make_scan(scene, synth.make_pose(10_000 * rank + f), args.sensor, seed=10_000 * rank + f) for f in range(F)]
+    host_scans = synth.bench_frames(scene, args.sensor, F, rank)
     cols = torch.empty((F, 3, n_pts), dtype=torch.float32, device=dev)
     for f, s in enumerate(host_scans):
         cols[f, 0] = torch.from_numpy(s.x)

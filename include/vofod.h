@@ -50,7 +50,8 @@ typedef enum vofod_status {
   VOFOD_ERR_PAUSED = 9,               /* raycast__pause / sepclusters__pause: :1400-1404, :1128-1132 */
   VOFOD_ERR_NOT_PENDING = 10,         /* *_finish without a matching *_begin */
   VOFOD_ERR_EMPTY = 11,               /* sepclusters: thresholded map cloud empty: :1155-1159 */
-  VOFOD_ERR_MAP_RANGE = 12            /* a weighted point fell outside the voxel map (vector::at would throw: voxel_map.cpp:116-117) */
+  VOFOD_ERR_MAP_RANGE = 12,           /* a weighted point fell outside the voxel map (vector::at would throw: voxel_map.cpp:116-117) */
+  VOFOD_ERR_BUSY = 13                 /* a submitted batch (vofod_batch_submit) still reads the state this call would overwrite: collect it first */
 } vofod_status;
 
 typedef struct vofod_handle vofod_handle;

@@ -29,6 +29,7 @@ ERR_PAUSED = 9
 ERR_NOT_PENDING = 10
 ERR_EMPTY = 11
 ERR_MAP_RANGE = 12
+ERR_BUSY = 13
 
 MEM_HOST, MEM_DEVICE = 0, 1
 MAP_VOXELS, MAP_FLAGS, MAP_RAYCAST = 0, 1, 2

@@ -714,12 +714,34 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
   return VOFOD_OK;
 }
 
+// A submitted batch reads the voxel map, its images and (ticket 0) the synchronous workspace until it is collected.
+// Calls that would overwrite that state are refused instead of racing it (the reference serialises them on m_voxels_mtx;
+// a batch in flight is "inside the lock" until vofod_batch_collect).
+static int busy_check(vofod_handle* h, bool uses_ws0, bool writes_map)
+{
+  if (uses_ws0 && h->ws.pending)
+  {
+    h->err = "ticket 0 is in flight on the synchronous workspace: collect it first";
+    return VOFOD_ERR_BUSY;
+  }
+  if (writes_map)
+    for (int t = 0; t < vofod_handle::MAX_INFLIGHT; t++)
+      if (h->slot(t)->pending)
+      {
+        h->err = "a submitted batch still reads the voxel map: collect it first";
+        return VOFOD_ERR_BUSY;
+      }
+  return VOFOD_OK;
+}
+
 int vofod_reset(vofod_handle* h)
 {
   if (!h)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, true); b != VOFOD_OK)
+    return b;
   const int r = do_reset(h);
   h->sure_background_sufficient = false;
   h->background_pts_sufficient = false;
@@ -762,6 +784,8 @@ int vofod_load_apriori(vofod_handle* h, const float* xyz, size_t n)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, true); b != VOFOD_OK)
+    return b;
   if (n)
   {
     float* d = nullptr;
@@ -776,6 +800,7 @@ int vofod_load_apriori(vofod_handle* h, const float* xyz, size_t n)
   h->mapbits_valid = false;
   return VOFOD_OK;
 }
+
 
 static float* pick_map(vofod_handle* h, int which)
 {
@@ -808,6 +833,8 @@ int vofod_update_ground(vofod_handle* h, float range, float min_range, float max
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, false, true); b != VOFOD_OK)
+    return b;
   if (range <= min_range && range >= max_range)  // vofod_nodelet.cpp:585, as written
     return VOFOD_OK;
   // one voxel at the range-finder's rate: read, blend on the host in the reference's double expression, write back
@@ -832,6 +859,8 @@ int vofod_write_map(vofod_handle* h, int which, const float* src, size_t n)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, false, true); b != VOFOD_OK)
+    return b;
   float* m = pick_map(h, which);
   if (!m || n != h->mg.n)
     return VOFOD_ERR_SIZE_MISMATCH;
@@ -847,6 +876,8 @@ int vofod_process_scan(vofod_handle* h, const vofod_scan* scan, const float tf[1
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, !(flags & VOFOD_SCAN_NO_MAP_UPDATE)); b != VOFOD_OK)
+    return b;
   *n_out = 0;
   return process_frames(h, h->ws, FRAMES_SYNC, scan, tf, 1, flags, out, cap, nullptr, n_out, dbg);
 }
@@ -858,6 +889,8 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, false); b != VOFOD_OK)
+    return b;
   *n_out = 0;
   int ret = VOFOD_OK;
   size_t total = 0;
@@ -942,6 +975,8 @@ int vofod_raycast_begin(vofod_handle* h, const vofod_scan* scan, const float tf[
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, false); b != VOFOD_OK)
+    return b;
   return raycast_begin_locked(h, scan, tf);
 }
 
@@ -951,6 +986,8 @@ int vofod_raycast_finish(vofod_handle* h)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, false, true); b != VOFOD_OK)
+    return b;
   return raycast_finish_locked(h);
 }
 
@@ -960,6 +997,8 @@ int vofod_sepclusters_begin(vofod_handle* h, int* sure)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, false); b != VOFOD_OK)
+    return b;
   return sepclusters_begin_locked(h, sure);
 }
 
@@ -969,6 +1008,8 @@ int vofod_sepclusters_finish(vofod_handle* h)
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, true); b != VOFOD_OK)
+    return b;
   return sepclusters_finish_locked(h);
 }
 
@@ -979,6 +1020,8 @@ int vofod_voxel_grid_weighted(vofod_handle* h, const vofod_cloud_view* in, float
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, false); b != VOFOD_OK)
+    return b;
   GridParams g;
   FrameHdr hdr{};
   const float l[3] = {leaf, leaf, leaf};
@@ -1007,6 +1050,8 @@ int vofod_voxel_grid_counted(vofod_handle* h, const vofod_cloud_view* in, float 
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, false); b != VOFOD_OK)
+    return b;
   GridParams g;
   FrameHdr hdr{};
   const float l[3] = {leaf, leaf, leaf};
@@ -1041,6 +1086,8 @@ int vofod_cluster(vofod_handle* h, const vofod_point_xyzr* pts, const uint32_t* 
     return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(h->mtx);
   (void)hipSetDevice(h->device);
+  if (const int b = busy_check(h, true, false); b != VOFOD_OK)
+    return b;
   if (n_clusters)
     *n_clusters = 0;
   if (n == 0)

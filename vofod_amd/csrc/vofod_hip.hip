@@ -186,6 +186,8 @@ struct Workspace
   bool finalize_fused = false;  // ... and the cluster table / candidate list too
   bool closefar_fused = false;  // launch_cluster answered hasCloseTo as well (dilated image inside k_flatten)
   bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
+  bool rerun = false;          // the next launch repeats this workspace's batch (LDS overflow): frame arguments and staged columns are kept
+  void* d_members_big = nullptr;  // vox_cap gathered candidate members: read-back of a frame whose list exceeds the packed slot
   // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
   bool pending = false;
   uint32_t job_n = 0;
@@ -195,7 +197,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -260,6 +262,7 @@ struct Workspace
     sa.keys = d_ptrank;
     WS_ALLOC(d_stage, sizeof(float) * 5 * static_cast<size_t>(F) * pt_cap);
     WS_ALLOC(d_packed, sizeof(PackedFrame) * F);
+    WS_ALLOC(d_members_big, sizeof(CandMemberX) * static_cast<size_t>(std::max<uint32_t>(vox_cap, 1)));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -294,7 +297,7 @@ struct HostCluster
 struct vofod_handle
 {
   unsigned long long *d_prof_slab = nullptr, *d_prof_ccl = nullptr;  // stamp buffers of the VOFOD_LDS_PROF diagnostics
-  bool lds_ccl_off = false;  // a frame overflowed the LDS clustering kernel once: stay on the global-memory kernels
+  bool lds_ccl_off = false;  // a frame of the batch just collected overflowed the LDS kernels: the NEXT launch (its re-run) takes the global-memory kernels, then the flag drops
   std::mutex mtx;
   vofod_static_params sp{};
   vofod_dyn_params dp{};
@@ -321,6 +324,7 @@ struct vofod_handle
   unsigned long long* d_counter = nullptr;  // scratch words
   unsigned long long *d_bgcount = nullptr, *h_bgcount = nullptr;  // MB_SLOTS partial nVoxelsOver counters (64 B apart); host pinned copy
   bool bgcount_fresh = false;
+  hipEvent_t ev_bgcount = nullptr;  // recorded behind the device-to-host copy of the background count: waited for before the count is consumed
   unsigned long long* h_counter = nullptr;  // pinned
   bool mapbits_valid = false;
   float mapbits_thr = 0;
@@ -1022,7 +1026,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     bp.bricks_cap = ws.bricks_cap;
     // Batches of independent frames: the whole brick graph of a frame is clustered inside one workgroup's LDS
     // (kernels_brick_lds.h).  VOFOD_BRICK_LDS=0 keeps the global-memory kernels.
-    const uint32_t lb_limit = std::getenv("VOFOD_LDS_MAX_BRICKS") ? std::min<uint32_t>(LB_MAX, std::atoi(std::getenv("VOFOD_LDS_MAX_BRICKS"))) : LB_MAX;
+    static const uint32_t lb_limit = std::getenv("VOFOD_LDS_MAX_BRICKS") ? std::min<uint32_t>(LB_MAX, std::atoi(std::getenv("VOFOD_LDS_MAX_BRICKS"))) : LB_MAX;
     if (ws.lean_emit)
     {
       (void)allow_lds;
@@ -1081,9 +1085,16 @@ int ensure_mapbits(vofod_handle* h, float thr)
 {
   if (h->mapbits_valid && h->mapbits_thr == thr)
     return VOFOD_OK;
+  // the image is shared with every batch in flight (their chains read it from streams of their own): let them finish first
+  for (int t = 0; t < vofod_handle::MAX_INFLIGHT; t++)
+    if (h->slot(t)->pending && h->slot(t)->ev_done)
+      HIPCHK(hipEventSynchronize(h->slot(t)->ev_done));
   HIPCHK(hipMemsetAsync(h->d_bgcount, 0, sizeof(unsigned long long) * 8 * MB_SLOTS, h->stream));
   KLAUNCH(h, k_mapbits, dim3(1024), dim3(256), h->d_map, h->mg.n, thr, h->d_mapbits, h->d_bgcount);
   HIPCHK(hipMemcpyAsync(h->h_bgcount, h->d_bgcount, sizeof(unsigned long long) * 8 * MB_SLOTS, hipMemcpyDeviceToHost, h->stream));
+  if (!h->ev_bgcount)
+    HIPCHK(hipEventCreateWithFlags(&h->ev_bgcount, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(h->ev_bgcount, h->stream));
   h->bgcount_fresh = true;
   h->mapbits_gen++;
   h->mapbits_valid = true;
@@ -1311,10 +1322,20 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   auto t0 = clk::now();
   static const bool trace = std::getenv("VOFOD_TRACE") != nullptr;
   double tr_launch = 0, tr_sync1 = 0, tr_prep = 0, tr_explore = 0, tr_a = 0, tr_b = 0, tr_c = 0;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  struct DbgEvents  // destroyed on every return path
+  {
+    hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~DbgEvents()
+    {
+      for (auto& x : e)
+        if (x)
+          (void)hipEventDestroy(x);
+    }
+  } dbg_events;
+  hipEvent_t* ev = dbg_events.e;
   if (dbg)
-    for (auto& e : ev)
-      HIPCHK(hipEventCreate(&e));
+    for (int i = 0; i < 5; i++)
+      HIPCHK(hipEventCreate(&ev[i]));
 
   GridParams g;
   int r = VOFOD_OK;
@@ -1343,7 +1364,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   if (phase != FRAMES_COLLECT)
   {
   ChainStream chain_guard(h, my_stream);
-  if (two_chains && phase == FRAMES_LAUNCH && !h->mapbits_valid)
+  if (two_chains && phase == FRAMES_LAUNCH && !(h->mapbits_valid && h->mapbits_thr == thr_new))
   {
     // the occupancy image is shared by both chains: make sure it is complete before a second stream reads it
     r = ensure_mapbits(h, thr_new);
@@ -1352,13 +1373,16 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   // ---- stage inputs, K1-K6 (filterAndTransform :621-684)
-  for (uint32_t f = 0; f < n; f++)
+  // (the re-run of a batch that overflowed the LDS kernels keeps the frame arguments and the staged columns of its first
+  // launch: the caller's host buffers need not outlive vofod_batch_submit)
+  for (uint32_t f = 0; f < n && !ws.rerun; f++)
   {
     const vofod_scan& s = scans[f];
     const int r = stage_cloud(h, ws, f, s.x, s.y, s.z, nullptr, nullptr, s.stride_bytes, npts, s.memspace, FA_SCAN, tfs + 12 * f);
     if (r != VOFOD_OK)
       return r;
   }
+  ws.rerun = false;
   const float leaf[3] = {sp.voxel_size, sp.voxel_size, sp.voxel_size};
   const int zero[3] = {0, 0, 0};
   float align_center[3];
@@ -1405,7 +1429,9 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     // Fusing the brick registration into k_emit was measured slower (194 us vs 96 + 50 us for 32 frames: the returning
     // atomicOr sits inside the load-balanced emission loop), so it stays a kernel of its own unless VOFOD_FUSE_BRICKS=1.
     static const bool fuse = std::getenv("VOFOD_FUSE_BRICKS") && std::atoi(std::getenv("VOFOD_FUSE_BRICKS")) == 1;
-    r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false, (fuse && want_bricks(ct, ws)) ? &bp : nullptr, plan_lds_ccl(h, ct, ws, no_update && n >= 4));
+    const bool lds_plan = plan_lds_ccl(h, ct, ws, no_update && n >= 4);
+    h->lds_ccl_off = false;  // one-shot: only the re-run of the batch that overflowed stays off the LDS kernels
+    r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false, (fuse && want_bricks(ct, ws)) ? &bp : nullptr, lds_plan);
   }
   if (r != VOFOD_OK)
     return r;
@@ -1484,6 +1510,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       // a frame held more bricks than the LDS clustering kernel takes: nothing of this batch was used (batches never
       // update the map); the caller runs it again on the global-memory kernels
       h->lds_ccl_off = true;
+      ws.rerun = true;
       ws.bitmap_clean = false;
       return CCL_RETRY_STATUS;
     }
@@ -1492,6 +1519,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
 
   if (h->bgcount_fresh)
   {
+    if (h->ev_bgcount)
+      HIPCHK(hipEventSynchronize(h->ev_bgcount));  // the copy may have been enqueued on another chain's stream
     uint64_t t = 0;
     for (int i = 0; i < MB_SLOTS; i++)
       t += h->h_bgcount[8 * i];
@@ -1520,8 +1549,6 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
       dev_ms[i] = ms;
     }
-    for (auto& e : ev)
-      (void)hipEventDestroy(e);
   }
 
   // ---- tail: classifyClusters :961 + extractDetections :963.
@@ -1557,12 +1584,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     if (hdr.n_cand > SPEC_M)
     {
       members_big[f].resize(hdr.n_cand);
-      CandMemberX* d_tmp = nullptr;
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_tmp), sizeof(CandMemberX) * hdr.n_cand));
+      CandMemberX* d_tmp = static_cast<CandMemberX*>(ws.d_members_big);  // n_cand <= V <= vox_cap: sized with the workspace
       KLAUNCH(h, k_gather_members, dim3((hdr.n_cand + 255) / 256), dim3(256), g, f, hdr.n_cand, ws.d_cand, ws.va, d_tmp);
       HIPCHK(hipMemcpyAsync(members_big[f].data(), d_tmp, sizeof(CandMemberX) * hdr.n_cand, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
-      (void)hipFree(d_tmp);
     }
   }
   // phase B (parallel over frames): canonical order, member index, boxes and gates, the frame's explore jobs

@@ -154,13 +154,15 @@ class VoFOD:
         self._check(self.lib.write_map(self.h, which, capi.ptr(a), a.size), "vofod_write_map")
 
     # ------------------------------------------------------------- hot path
-    def _mk_dbg(self, n_points: int):
+    def _mk_dbg(self, n_points: int, clusters_cap: int | None = None):
+        """debug buffers of one frame; `clusters_cap` bounds the cluster table (default: one per point, the worst case)"""
+        n_cl = n_points if clusters_cap is None else clusters_cap
         w = np.zeros(n_points, dtype=capi.POINT_XYZR)
         lab = np.zeros(n_points, dtype=np.uint32)
-        cl = np.zeros(n_points, dtype=capi.CLUSTER_INFO)
+        cl = np.zeros(n_cl, dtype=capi.CLUSTER_INFO)
         d = capi.ScanDebug()
         d.weighted, d.labels, d.weighted_cap = capi.ptr(w), capi.ptr(lab), n_points
-        d.clusters, d.clusters_cap = capi.ptr(cl), n_points
+        d.clusters, d.clusters_cap = capi.ptr(cl), n_cl
         return d, (w, lab, cl)
 
     @staticmethod
@@ -189,7 +191,7 @@ class VoFOD:
         out = dets[: n_out.value].copy()
         return (out, self._dbg_dict(dbg, bufs)) if debug else out
 
-    def process_batch(self, scans: Sequence[ScanData], tfs: np.ndarray, debug: bool = False, det_cap: int = 4096):
+    def process_batch(self, scans: Sequence[ScanData], tfs: np.ndarray, debug: bool = False, det_cap: int = 4096, clusters_cap: int | None = None):
         n = len(scans)
         arr = (capi.Scan * n)(*[s.as_c() for s in scans])
         tfa = np.ascontiguousarray(tfs, dtype=np.float32).reshape(n, 12)
@@ -201,7 +203,7 @@ class VoFOD:
         if debug:
             dbgs = (capi.ScanDebug * n)()
             for f in range(n):
-                d, b = self._mk_dbg(scans[f].width * scans[f].height)
+                d, b = self._mk_dbg(scans[f].width * scans[f].height, clusters_cap)
                 dbgs[f] = d
                 bufs.append(b)
         st = self.lib.process_batch(self.h, arr, capi.ptr(tfa), n, capi.ptr(dets), det_cap, capi.ptr(per), C.byref(n_out), dbgs)

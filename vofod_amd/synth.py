@@ -140,14 +140,21 @@ def make_scan(scene: Scene, tf: np.ndarray, sensor: str = "os1-128", seed: int =
     return SynthScan(scan=scan, tf=tf.astype(np.float32), x=x, y=y, z=z, intensity=intensity, range=range_mm)
 
 
-def apriori_points(scene: Scene, voxel_size: float, n_voxels: int | None = None, seed: int = 0) -> np.ndarray:
+def apriori_points(scene: Scene, voxel_size: float, n_voxels: int | None = None, seed: int = 0, solid_ground_to: float | None = None) -> np.ndarray:
     """World-frame points on the ground sheet and on the static boxes' shells, one per
-    voxel-sized cell (stand-in for the downsampled static cloud of vofod_nodelet.cpp:332-341)."""
+    voxel-sized cell (stand-in for the downsampled static cloud of vofod_nodelet.cpp:332-341).
+    `solid_ground_to`: also fill the ground below z = 0 down to that height, one point per voxel layer (a surveyed
+    terrain volume: what it takes to reach the 1 M apriori voxels of BASELINE.json configs[2] at 0.25 m)."""
     rng = np.random.default_rng(seed + 15485863)
     vs = voxel_size
     x0, x1, y0, y1 = scene.ground_rect
     gx, gy = np.meshgrid(np.arange(x0 + vs / 2, x1, vs), np.arange(y0 + vs / 2, y1, vs), indexing="ij")
     pts = [np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 0.0 + vs * 0.25)], axis=1)]
+    if solid_ground_to is not None:
+        zl = vs * 0.25 - vs
+        while zl > solid_ground_to:
+            pts.append(np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, zl)], axis=1))
+            zl -= vs
     for b in scene.boxes[: scene.n_static]:
         xs = np.arange(b[0] + vs / 2, b[3], vs)
         ys = np.arange(b[1] + vs / 2, b[4], vs)
@@ -195,3 +202,35 @@ def scan_sequence(scene: Scene, sensor: str, n: int, seed0: int = 0, xy=(0.0, 0.
         tf = make_pose(seed0 + k, xy=xy)
         out.append(make_scan(scene, tf, sensor, seed=seed0 + k))
     return out
+
+
+# ---------------------------------------------------------------------------- bench workload
+
+BENCH_SCENE_SEED = 0
+BENCH_WARM_SEED0 = 1000
+
+
+def bench_scene() -> Scene:
+    """the scene bench.py measures on (BASELINE.json configs[1]/[3]): seed 0, three floating targets"""
+    return make_scene(BENCH_SCENE_SEED, n_targets=3)
+
+
+def bench_frames(scene: Scene, sensor: str, n: int, rank: int = 0):
+    """the n independent scans of one rank's batch in bench.py: independent poses and noise seeds 10 000*rank + f"""
+    return [make_scan(scene, make_pose(10_000 * rank + f), sensor, seed=10_000 * rank + f) for f in range(n)]
+
+
+def warm_map(det, scene: Scene, sensor: str, n_scans: int, seed0: int = BENCH_WARM_SEED0):
+    """config 2 of SURVEY 8d: map pre-warmed by n scans with the raycast and sepclusters roles interleaved.
+    Works on any implementation of the C-ABI (bench.py warms the HIP detector, the tests hand the map to the oracle)."""
+    from . import capi
+
+    seed_ground(det)
+    for k, s in enumerate(scan_sequence(scene, sensor, n_scans, seed0=seed0)):
+        det.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+        if k % 2 == 1:
+            st, sure = det.sepclusters_begin(allow=(capi.ERR_EMPTY,))
+            if st == capi.OK and sure:
+                det.sepclusters_finish()
+    if det.status().raycast_pending:
+        det.raycast_finish(allow=(capi.ERR_RAYCAST_NO_DETECTION, capi.ERR_RAYCAST_EMPTY))
