@@ -132,7 +132,7 @@ def test_large_batch_falls_back_per_batch_when_a_frame_overflows_lds(oracle, hip
         names = _profiled_kernels(lib, dev)
         lib.profile_enable(dev.h, 0)
         if batch == 1:
-            assert any(n.startswith(("k_brick_ccl_lds", "k_frame_ccl")) for n in names), names  # no permanent latch
+            assert any(n.startswith(("k_brick_ccl_lds", "k_frame_lds")) for n in names), names  # no permanent latch
 
 
 def _profiled_kernels(lib, det):
@@ -192,7 +192,9 @@ def test_config5_os2_128x2048_at_01(oracle, hip):
     assert ref.raycast_begin(s0.scan, s0.tf) == dev.raycast_begin(s0.scan, s0.tf) == capi.OK
     ra, rb = ref.read_map(capi.MAP_RAYCAST), dev.read_map(capi.MAP_RAYCAST)
     assert np.count_nonzero(ra) > 1_000_000
-    np.testing.assert_allclose(rb, ra, rtol=2e-5, atol=2e-6)  # float-atomic accumulation order
+    # tolerance: float-atomic accumulation order.  2048 columns at 0.1 m put ~10^4 ray segments into the voxels
+    # next to the sensor: 2e-4 relative here (2e-5 holds for the 1024-column sensors of test_gpu_parity.py)
+    np.testing.assert_allclose(rb, ra, rtol=2e-4, atol=2e-6)
     del ra, rb
     dr, gr = ref.process_scan(s1.scan, s1.tf, debug=True)
     dh, gh = dev.process_scan(s1.scan, s1.tf, debug=True)

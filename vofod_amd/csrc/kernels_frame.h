@@ -1,0 +1,1266 @@
+// One frame = one workgroup, bricks first (gfx950: 160 KB of LDS per CU).
+//
+// Round 1's batched path walked the frame's 11 M-cell lattice in 1 Mi-cell LDS slabs (k_slab_emit: 11 x clear + mark +
+// scan of 128 KB, 1400 emission groups, 99.7 % of them empty) and then re-derived the brick graph from the voxel
+// records in a second kernel (k_brick_ccl_lds, phases A-C).  The lattice is sparse, the *brick* lattice (4x4x4 cells
+// per brick, 64 times fewer bits) is not large: a whole frame's brick bitmap fits LDS next to its occupied bricks.
+// So voxelisation (voxel_grid_weighted.cpp:122-188) runs brick-first and the clustering (vofod_nodelet.cpp:689-698)
+// continues on the very same LDS image:
+//   k_key2      one pass over the input columns: crops + transform (vofod_nodelet.cpp:625-655), cell of every
+//               surviving point (voxel_grid_weighted.cpp:131-136) as a *brick code* (brick id * 64 + bit inside the
+//               brick), appended in point order (8 consecutive points per thread: points of one ring that fall into
+//               one voxel / brick stay neighbours in the list);
+//   k_frame_lds 1  brick bitmap of the frame (one LDS atomic per run of codes in the same brick),
+//               2  popcount prefix: a brick's node index = its rank among the occupied bricks,
+//               3  occupancy words: OR of the codes into the node's 64-bit word; a code whose bit was set already is
+//                  an extra point of its voxel (weights, voxel_grid_weighted.cpp:181) and goes to a small record list,
+//               4  voxel ranks in the reference's key order (z, y, x) without ever sorting: nodes are ordered
+//                  (bz, by, bx); a brick row (bz, by) holds 16 lattice rows (yy, zz) = 16 channels; a segmented wave
+//                  scan over the nodes gives every (node, channel) its offset inside the lattice row, the row totals
+//                  go through a small per-frame table in global memory (L2) and one block scan in key order gives
+//                  every lattice row its base rank; then the voxel records (centre, weight 1, key, node) are stored
+//                  at their ranks and the extras add to their voxels' weights,
+//               D-E the clustering phases of k_brick_ccl_lds on the same bitmap / words (probe, octant test, exact test
+//                  across components only, LDS union-find, component minima, statistics, labels, cluster table).
+// A frame beyond the LDS capacities raises CCL_RETRY_STATUS: the host re-runs that batch on the general kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_brick_lds.h"
+#include "kernels_slab.h"
+
+namespace vk
+{
+
+constexpr int FR_THREADS = 1024;
+constexpr int FR_BW64 = LB_BITWORDS / 2;  // 64-bit words of the brick-lattice bitmap
+constexpr int FR_EREC = LB_MAX / 2;       // extras records kept in LDS (they share the union-find's storage)
+constexpr int FR_CHUNKS = LB_MAX / 64;    // 64-node chunks of the rank scans
+constexpr int FR_MAX_NBZ = 64;            // brick layers along z
+constexpr uint32_t FR_ROWS_MAX = 8192;    // brick rows (nby * nbz) the per-frame row tables cover
+constexpr uint32_t FR_CODE_NONE = 0xffffffffu;
+
+// per-frame scratch in global memory (L2-resident: touched sparsely)
+struct FrameScratch
+{
+  unsigned long long* rowT;  // [F][FR_ROWS_MAX][4]: per brick row, per zz: the four yy channel totals, 16 bits each
+  uint32_t* rowQ;            // [F][FR_ROWS_MAX][4]: rank of the first voxel of lattice rows (4 bz + zz, 4 by .. 4 by + 3)
+  uint32_t* bmin;            // [F][LB_MAX]: per node, the rank of the brick's first voxel
+};
+
+// ---- K1-K5a in one pass: brick codes of the surviving points ---------------------------------------------------
+constexpr int KEY2_THREADS = 256;
+constexpr int KEY2_PPT = 8;  // consecutive points per thread
+
+template <bool PACKED>
+__global__ __launch_bounds__(KEY2_THREADS) void k_key2(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameArgs& a = args[FRAME];
+  const FrameHdr& h = hdrs[FRAME];
+  if (h.n_in == 0)
+    return;
+  const uint32_t base_blk = BX * KEY2_THREADS * KEY2_PPT;
+  if (base_blk >= a.n)
+    return;
+  const uint32_t i0 = base_blk + threadIdx.x * KEY2_PPT;
+  float px[KEY2_PPT], py[KEY2_PPT], pz[KEY2_PPT];
+  if (PACKED && i0 + KEY2_PPT <= a.n)
+  {
+    // packed float columns, 16-byte aligned: two 16-byte loads per column and thread
+    const float4* cx = reinterpret_cast<const float4*>(a.x + static_cast<uint64_t>(i0) * 4);
+    const float4* cy = reinterpret_cast<const float4*>(a.y + static_cast<uint64_t>(i0) * 4);
+    const float4* cz = reinterpret_cast<const float4*>(a.z + static_cast<uint64_t>(i0) * 4);
+    const float4 x0 = cx[0], x1 = cx[1], y0 = cy[0], y1 = cy[1], z0 = cz[0], z1 = cz[1];
+    px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
+    py[0] = y0.x, py[1] = y0.y, py[2] = y0.z, py[3] = y0.w, py[4] = y1.x, py[5] = y1.y, py[6] = y1.z, py[7] = y1.w;
+    pz[0] = z0.x, pz[1] = z0.y, pz[2] = z0.z, pz[3] = z0.w, pz[4] = z1.x, pz[5] = z1.y, pz[6] = z1.z, pz[7] = z1.w;
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < KEY2_PPT; j++)
+    {
+      const uint32_t i = i0 + j;
+      const bool ok = i < a.n;
+      px[j] = ok ? ldf(a.x, a.stride, i) : 0.0f;  // (0,0,0) lies inside the exclude box; the index test below drops it anyway
+      py[j] = ok ? ldf(a.y, a.stride, i) : 0.0f;
+      pz[j] = ok ? ldf(a.z, a.stride, i) : 0.0f;
+    }
+  }
+  const int dx = h.div_b[0], dy = h.div_b[1], dz = h.div_b[2];
+  const int nbx = (dx + 3) >> 2, nby = (dy + 3) >> 2;
+  uint32_t code[KEY2_PPT];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < KEY2_PPT; j++)
+  {
+    code[j] = FR_CODE_NONE;
+    const float p0 = px[j], p1 = py[j], p2 = pz[j];
+    bool keep = i0 + j < a.n && isfinite(p0) && isfinite(p1) && isfinite(p2);
+    keep = keep && (p0 < g.ex_min[0] || p1 < g.ex_min[1] || p2 < g.ex_min[2] || p0 > g.ex_max[0] || p1 > g.ex_max[1] || p2 > g.ex_max[2]);
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
+      q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
+    keep = keep && !(q[0] < g.op_min[0] || q[1] < g.op_min[1] || q[2] < g.op_min[2] || q[0] > g.op_max[0] || q[1] > g.op_max[1] || q[2] > g.op_max[2]);
+    if (keep)
+    {
+      int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], h.offset[0]), g.inv[0])));
+      int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], h.offset[1]), g.inv[1])));
+      int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], h.offset[2]), g.inv[2])));
+      bool ok = true;
+      if (k0 < 0 || k0 >= dx || k1 < 0 || k1 >= dy || k2 < 0 || k2 >= dz)
+      {
+        // a rounding artefact outside the lattice: the reference aliases it through the linear index
+        // (voxel_grid_weighted.cpp:137); k_key / k_setbits do the same and drop what leaves the index range
+        const uint32_t key = static_cast<uint32_t>(k0 + k1 * dx + k2 * dx * dy);
+        ok = key < h.n_cells;
+        if (ok)
+          key_to_ijk(h, key, k0, k1, k2);
+      }
+      if (ok)
+        code[j] = (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
+    }
+    cnt += code[j] != FR_CODE_NONE;
+  }
+  // order-preserving block compaction, one global atomic per 2048 points
+  __shared__ uint32_t s_wsum[KEY2_THREADS / 64];
+  __shared__ uint32_t s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(cnt);
+  if (lane == 63)
+    s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t off = incl - cnt, total = 0;
+#pragma unroll
+  for (int w = 0; w < KEY2_THREADS / 64; w++)
+  {
+    const uint32_t x = s_wsum[w];
+    off += w < wave ? x : 0u;
+    total += x;
+  }
+  if (threadIdx.x == 0)
+    s_base = total ? atomicAdd(&sa.counts[2 * FRAME], total) : 0u;
+  __syncthreads();
+  uint32_t* out = sa.keys + static_cast<size_t>(FRAME) * pt_cap + s_base + off;
+#pragma unroll
+  for (int j = 0; j < KEY2_PPT; j++)
+    if (code[j] != FR_CODE_NONE)
+      *out++ = code[j];
+}
+
+// ---- helpers of k_frame_lds ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fr_node(const unsigned long long* bits64, const uint16_t* pre, uint32_t b)
+{
+  return pre[b >> 6] + __popcll(bits64[b >> 6] & ((1ull << (b & 63u)) - 1ull));
+}
+
+// the four yy channel counts of z layer zz of a brick word, 16 bits each (bit p of W = x + 4y + 16z)
+__device__ __forceinline__ unsigned long long fr_chan(unsigned long long W, int zz)
+{
+  uint32_t x = static_cast<uint32_t>(W >> (16 * zz)) & 0xffffu;
+  x = x - ((x >> 1) & 0x5555u);
+  x = (x & 0x3333u) + ((x >> 2) & 0x3333u);  // every nibble holds its popcount
+  return static_cast<unsigned long long>(x & 0xfu) | (static_cast<unsigned long long>((x >> 4) & 0xfu) << 16) | (static_cast<unsigned long long>((x >> 8) & 0xfu) << 32) |
+         (static_cast<unsigned long long>((x >> 12) & 0xfu) << 48);
+}
+
+// field-wise exclusive prefix of four 16-bit fields
+__device__ __forceinline__ unsigned long long fr_excl16(unsigned long long x) { return (x << 16) + (x << 32) + (x << 48); }
+__device__ __forceinline__ uint32_t fr_hsum16(unsigned long long x)
+{
+  return static_cast<uint32_t>(x & 0xffffu) + static_cast<uint32_t>((x >> 16) & 0xffffu) + static_cast<uint32_t>((x >> 32) & 0xffffu) + static_cast<uint32_t>(x >> 48);
+}
+
+__device__ __forceinline__ unsigned long long fr_shfl_up64(unsigned long long v, int s)
+{
+  const uint32_t lo = __shfl_up(static_cast<uint32_t>(v), s), hi = __shfl_up(static_cast<uint32_t>(v >> 32), s);
+  return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
+}
+
+__device__ __forceinline__ unsigned long long fr_shfl64(unsigned long long v, int src)
+{
+  const uint32_t lo = __shfl(static_cast<uint32_t>(v), src), hi = __shfl(static_cast<uint32_t>(v >> 32), src);
+  return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
+}
+
+// Segmented inclusive scan over the wave's lanes: four 64-bit values per lane, a segment starts at every lane whose
+// `head` is set.  Afterwards `head` tells whether a head sits at or before the lane (its segment began inside the wave).
+__device__ __forceinline__ void fr_segscan(unsigned long long v[4], bool& head, int lane)
+{
+  int f = head ? 1 : 0;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1)
+  {
+    unsigned long long t[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      t[q] = fr_shfl_up64(v[q], s);
+    const int ft = __shfl_up(f, s);
+    if (lane >= s)
+    {
+      if (!f)
+      {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          v[q] += t[q];
+      }
+      f |= ft;
+    }
+  }
+  head = f != 0;
+}
+
+// The wave's view of 64 consecutive nodes for the rank scans: channel counts P, their segmented (per brick row)
+// inclusive prefix A (carry of the rows that began in earlier chunks added), the node's brick row.
+struct FrNodes
+{
+  unsigned long long W;
+  unsigned long long P[4], A[4];
+  uint32_t xyz, row;
+  bool live, began_here, tail;
+};
+
+__device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_word, const uint32_t* s_xyz, uint32_t i, uint32_t n, int nby, int lane, const unsigned long long (*s_cin)[4],
+                                                 uint32_t chunk, bool with_carry)
+{
+  FrNodes o;
+  o.live = i < n;
+  o.W = o.live ? s_word[i] : 0ull;
+  o.xyz = o.live ? s_xyz[i] : 0u;
+  o.row = o.live ? (o.xyz >> 20) * static_cast<uint32_t>(nby) + ((o.xyz >> 10) & 1023u) : 0xffffffffu;
+  uint32_t prev = __shfl_up(o.row, 1);
+  if (lane == 0)
+  {
+    prev = 0xfffffffeu;
+    if (o.live && i > 0)
+    {
+      const uint32_t x = s_xyz[i - 1];
+      prev = (x >> 20) * static_cast<uint32_t>(nby) + ((x >> 10) & 1023u);
+    }
+  }
+  bool head = o.row != prev;
+  uint32_t next = __shfl_down(o.row, 1);
+  if (lane == 63)
+  {
+    next = 0xfffffffeu;
+    if (i + 1 < n)
+    {
+      const uint32_t x = s_xyz[i + 1];
+      next = (x >> 20) * static_cast<uint32_t>(nby) + ((x >> 10) & 1023u);
+    }
+  }
+  o.tail = o.live && next != o.row;
+#pragma unroll
+  for (int zz = 0; zz < 4; zz++)
+    o.A[zz] = o.P[zz] = fr_chan(o.W, zz);
+  fr_segscan(o.A, head, lane);
+  o.began_here = head;
+  if (with_carry && !head)
+  {
+#pragma unroll
+    for (int zz = 0; zz < 4; zz++)
+      o.A[zz] += s_cin[chunk][zz];
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
+                                                         VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
+                                                         const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
+                                                         const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,
+                                                         CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof)
+{
+  __shared__ __attribute__((aligned(16))) unsigned long long s_bits64[FR_BW64 + 2];  // brick-lattice bitmap, bit = linear brick id
+  __shared__ uint16_t s_pre[FR_BW64];                                                // exclusive popcount prefix per 64-bit word
+  __shared__ unsigned long long s_word[LB_MAX];                                      // node -> occupancy word; phase E: component minima / statistics
+  __shared__ uint32_t s_xyz[LB_MAX];                                                 // node -> brick coordinates, 10 bits each
+  __shared__ __attribute__((aligned(8))) uint32_t s_x2[FR_EREC];                     // extras records (phases 3-4), then the 16-bit union-find
+  __shared__ LbTables s_tab;
+  __shared__ unsigned long long s_cin[FR_CHUNKS + 1][4];  // per chunk: tail sums of its last brick row, then the carry into the chunk
+  __shared__ uint32_t s_cflag[FR_CHUNKS + 1];
+  __shared__ uint32_t s_wsum[FR_THREADS / 64];
+  __shared__ uint32_t s_n, s_nh, s_no, s_ne;
+  uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bits64);
+  uint16_t* s_par = reinterpret_cast<uint16_t*>(s_x2);
+  const uint32_t FRAME = blockIdx.x;
+  FrameHdr& h = hdrs[FRAME];
+  const uint32_t n_keys = sa.counts[2 * FRAME];
+  if (h.n_in == 0 || n_keys == 0)
+    return;  // k_init_hdr left V = C = 0
+  const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
+  uint32_t* labels = labels_all + static_cast<size_t>(FRAME) * g.vox_cap;
+  uint32_t* s_cmin = reinterpret_cast<uint32_t*>(s_word);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
+  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2, nbz = (h.div_b[2] + 3) >> 2;
+  const uint32_t nb_total = static_cast<uint32_t>(nbx) * nby * nbz;
+#define FR_STAMP(i)     \
+  if (prof && tid == 0) \
+  prof[static_cast<size_t>(FRAME) * 32 + (i)] = wall_clock64()
+  FR_STAMP(0);
+  if (static_cast<long long>(nbx) * nby * nbz > static_cast<long long>(LB_BITWORDS) * 32 || nbx > 1023 || nby > 1023 || nbz > FR_MAX_NBZ ||
+      static_cast<uint32_t>(nby) * nbz > FR_ROWS_MAX)
+  {
+    if (tid == 0)
+    {
+      h.status = CCL_RETRY_STATUS;
+      h.V = 0;  // the frame is empty for the rest of the chain; the host re-runs the batch
+    }
+    return;
+  }
+  for (int s = tid; s < FR_BW64 + 2; s += FR_THREADS)
+    s_bits64[s] = 0ull;
+  for (int s = tid; s < static_cast<int>(sizeof(LbTables) / 4); s += FR_THREADS)
+    reinterpret_cast<uint32_t*>(&s_tab)[s] = reinterpret_cast<const uint32_t*>(tab)[s];
+  if (tid == 0)
+  {
+    s_ne = 0;
+    s_nh = 0;
+    s_no = 0;
+  }
+  __syncthreads();
+  const uint32_t* codes = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
+  uint32_t* extras_g = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
+  constexpr int KPT = 8;  // consecutive codes per thread and round
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(codes) & 15u) == 0u;
+  auto load_codes = [&](uint32_t base, uint32_t c[KPT]) {
+    if (vec_ok && base + KPT <= n_keys)
+    {
+      const uint4 a = *reinterpret_cast<const uint4*>(codes + base), b = *reinterpret_cast<const uint4*>(codes + base + 4);
+      c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+        c[u] = base + u < n_keys ? codes[base + u] : FR_CODE_NONE;
+    }
+  };
+  // ---- 1: the occupied bricks.  Consecutive codes of a thread mostly share their brick: one LDS atomic per run.
+  for (uint32_t base = tid * KPT; base < n_keys; base += FR_THREADS * KPT)
+  {
+    uint32_t c[KPT];
+    load_codes(base, c);
+    uint32_t cur = FR_CODE_NONE;
+#pragma unroll
+    for (int u = 0; u < KPT; u++)
+    {
+      if (c[u] == FR_CODE_NONE)
+        continue;
+      const uint32_t b = c[u] >> 6;
+      if (b != cur)
+      {
+        if (cur != FR_CODE_NONE)
+          atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+        cur = b;
+      }
+    }
+    if (cur != FR_CODE_NONE)
+      atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+  }
+  __syncthreads();
+  FR_STAMP(1);
+  // ---- 2: node indices = ranks of the set bits
+  constexpr int WPT = (FR_BW64 + FR_THREADS - 1) / FR_THREADS;  // consecutive 64-bit words per thread
+  {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int r = 0; r < WPT; r++)
+      if (tid * WPT + r < FR_BW64)
+        cnt += __popcll(s_bits64[tid * WPT + r]);
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (lane == 63)
+      s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < FR_THREADS / 64; w++)
+    {
+      const uint32_t x = s_wsum[w];
+      base += w < wave ? x : 0u;
+      total += x;
+    }
+    if (tid == 0)
+      s_n = total;
+    if (total > lb_limit)  // <= LB_MAX (lower only in the tests of the fallback)
+    {
+      if (tid == 0)
+      {
+        h.status = CCL_RETRY_STATUS;
+        h.n_bricks = total;
+        h.V = 0;
+      }
+      return;
+    }
+    uint32_t run = base + incl - cnt;
+#pragma unroll
+    for (int r = 0; r < WPT; r++)
+      if (tid * WPT + r < FR_BW64)
+      {
+        s_pre[tid * WPT + r] = static_cast<uint16_t>(run);
+        run += __popcll(s_bits64[tid * WPT + r]);
+      }
+    for (uint32_t i = tid; i < total; i += FR_THREADS)
+      s_word[i] = 0ull;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  const uint32_t n_chunks = (n + 63u) >> 6;
+  FR_STAMP(2);
+  // ---- 3: occupancy words.  A thread ORs the run of its consecutive codes that share a brick with one LDS atomic per
+  // 32-bit half; a code whose bit is set already (inside the run, or in the word as the atomic returns it) is an extra
+  // point of its voxel: record = code | (points - 1) << 25.
+  {
+    auto push = [&](uint32_t rec) {
+      const uint32_t p = atomicAdd(&s_ne, 1u);
+      if (p < static_cast<uint32_t>(FR_EREC))
+        s_x2[p] = rec;
+      else
+        extras_g[atomicAdd(&sa.counts[2 * FRAME + 1], 1u)] = rec;  // the few records beyond the LDS list
+    };
+    auto flush = [&](uint32_t b, unsigned long long acc) {
+      const uint32_t node = fr_node(s_bits64, s_pre, b);
+      const uint32_t bz = b / static_cast<uint32_t>(nbx * nby);
+      const uint32_t brem = b - bz * static_cast<uint32_t>(nbx * nby);
+      const uint32_t by = brem / static_cast<uint32_t>(nbx);
+      s_xyz[node] = (brem - by * nbx) | (by << 10) | (bz << 20);  // every run of the brick writes the same value
+      uint32_t* w32 = reinterpret_cast<uint32_t*>(&s_word[node]);
+      const uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
+      if (lo)
+      {
+        uint32_t d = atomicOr(&w32[0], lo) & lo;
+        while (d)
+        {
+          const int bit = __ffs(static_cast<int>(d)) - 1;
+          d &= d - 1;
+          push((b << 6) | static_cast<uint32_t>(bit));
+        }
+      }
+      if (hi)
+      {
+        uint32_t d = atomicOr(&w32[1], hi) & hi;
+        while (d)
+        {
+          const int bit = __ffs(static_cast<int>(d)) - 1;
+          d &= d - 1;
+          push((b << 6) | static_cast<uint32_t>(bit + 32));
+        }
+      }
+    };
+    for (uint32_t base = tid * KPT; base < n_keys; base += FR_THREADS * KPT)
+    {
+      uint32_t c[KPT];
+      load_codes(base, c);
+      uint32_t cur = FR_CODE_NONE, last = FR_CODE_NONE, dups = 0;
+      unsigned long long acc = 0ull;
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+      {
+        if (c[u] == FR_CODE_NONE)
+          continue;
+        if (c[u] == last)
+        {
+          dups++;
+          continue;
+        }
+        if (dups)
+          push(last | ((dups - 1u) << 25));
+        dups = 0;
+        last = c[u];
+        const uint32_t b = c[u] >> 6;
+        if (b != cur)
+        {
+          if (cur != FR_CODE_NONE)
+            flush(cur, acc);
+          cur = b;
+          acc = 0ull;
+        }
+        const unsigned long long m = 1ull << (c[u] & 63u);
+        if (acc & m)
+          push(c[u]);  // the voxel came up earlier in this run (not as the previous code)
+        else
+          acc |= m;
+      }
+      if (dups)
+        push(last | ((dups - 1u) << 25));
+      if (cur != FR_CODE_NONE)
+        flush(cur, acc);
+    }
+  }
+  __syncthreads();
+  FR_STAMP(3);
+  // ---- 4: ranks in key order.  Pass a: per 64-node chunk the sums of its last brick row (rows may span chunks).
+  for (uint32_t ch = wave; ch < n_chunks; ch += FR_THREADS / 64)
+  {
+    const FrNodes nd = fr_load_nodes(s_word, s_xyz, ch * 64u + lane, n, nby, lane, s_cin, ch, false);
+    if (lane == 63)
+    {
+#pragma unroll
+      for (int zz = 0; zz < 4; zz++)
+        s_cin[ch + 1][zz] = nd.A[zz];  // staged one slot up: slot k + 1 becomes the carry into chunk k + 1
+      s_cflag[ch + 1] = nd.began_here ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (wave == 0)
+  {
+    // carry into chunk k + 1 = S(k) = tail(k) + (the tail row began inside chunk k ? 0 : S(k - 1)): a segmented scan again
+    unsigned long long carry[4] = {0ull, 0ull, 0ull, 0ull};
+    for (uint32_t k0 = 0; k0 < n_chunks; k0 += 64)
+    {
+      const uint32_t k = k0 + lane;
+      unsigned long long v[4];
+      bool hd = true;
+      if (k < n_chunks)
+      {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+          v[zz] = s_cin[k + 1][zz];
+        hd = s_cflag[k + 1] != 0u;
+      }
+      else
+      {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+          v[zz] = 0ull;
+      }
+      fr_segscan(v, hd, lane);
+      if (!hd)
+      {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+          v[zz] += carry[zz];
+      }
+      if (k < n_chunks)
+      {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+          s_cin[k + 1][zz] = v[zz];
+      }
+#pragma unroll
+      for (int zz = 0; zz < 4; zz++)
+        carry[zz] = fr_shfl64(v[zz], 63);
+    }
+    if (lane < 4)
+      s_cin[0][lane] = 0ull;
+  }
+  __syncthreads();
+  // Pass b: row totals -> global row table (dense index brick row = bz * nby + by; only occupied rows are written / read)
+  unsigned long long* rowT = fs.rowT + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
+  uint32_t* rowQ = fs.rowQ + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
+  uint32_t* bmin_g = fs.bmin + static_cast<size_t>(FRAME) * LB_MAX;
+  for (uint32_t ch = wave; ch < n_chunks; ch += FR_THREADS / 64)
+  {
+    const FrNodes nd = fr_load_nodes(s_word, s_xyz, ch * 64u + lane, n, nby, lane, s_cin, ch, true);
+    if (nd.tail)
+    {
+      ulonglong2* dst = reinterpret_cast<ulonglong2*>(rowT + static_cast<size_t>(nd.row) * 4);
+      dst[0] = make_ulonglong2(nd.A[0], nd.A[1]);
+      dst[1] = make_ulonglong2(nd.A[2], nd.A[3]);
+    }
+  }
+  __syncthreads();
+  FR_STAMP(4);
+  // Pass c: base rank of every lattice-row group in key order: q = (bz * 4 + zz) * nby + by
+  uint32_t V = 0;
+  {
+    const uint32_t nq = 4u * static_cast<uint32_t>(nby) * nbz;
+    const uint32_t qpt = (nq + FR_THREADS - 1) / FR_THREADS;  // <= 32
+    const uint32_t q0 = tid * qpt, q1 = min(q0 + qpt, nq);
+    auto row_sum = [&](uint32_t q, uint32_t& r_out, uint32_t& zz_out) -> uint32_t {
+      const uint32_t plane = q / static_cast<uint32_t>(nby);
+      const uint32_t by = q - plane * nby, bz = plane >> 2, zz = plane & 3u;
+      const uint32_t r = bz * nby + by;
+      r_out = r;
+      zz_out = zz;
+      const uint32_t b0 = r * nbx, b1 = b0 + nbx;
+      const uint32_t n0 = fr_node(s_bits64, s_pre, b0);
+      const uint32_t n1 = b1 < nb_total ? fr_node(s_bits64, s_pre, b1) : n;
+      return n1 != n0 ? fr_hsum16(rowT[static_cast<size_t>(r) * 4 + zz]) : 0xffffffffu;  // 0xffffffff: the brick row is empty
+    };
+    uint32_t sum = 0;
+    for (uint32_t q = q0; q < q1; q++)
+    {
+      uint32_t r, zz;
+      const uint32_t s = row_sum(q, r, zz);
+      sum += s == 0xffffffffu ? 0u : s;
+    }
+    const uint32_t incl = wave_incl_scan(sum);
+    if (lane == 63)
+      s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < FR_THREADS / 64; w++)
+    {
+      const uint32_t x = s_wsum[w];
+      run += w < wave ? x : 0u;
+      V += x;
+    }
+    for (uint32_t q = q0; q < q1; q++)
+    {
+      uint32_t r, zz;
+      const uint32_t s = row_sum(q, r, zz);
+      if (s != 0xffffffffu)
+      {
+        rowQ[static_cast<size_t>(r) * 4 + zz] = run;
+        run += s;
+      }
+    }
+  }
+  if (V > g.vox_cap)
+  {
+    if (tid == 0)
+    {
+      h.status = VOFOD_ERR_CAPACITY;  // as k_scan_b
+      h.V = 0;
+    }
+    return;
+  }
+  __syncthreads();
+  FR_STAMP(5);
+  // Pass d: the voxel records leave at their ranks (voxel_grid_weighted.cpp:171-188): centre, weight 1 (+ extras below),
+  // lattice key, node of the brick (for the label pass)
+  for (uint32_t ch = wave; ch < n_chunks; ch += FR_THREADS / 64)
+  {
+    const uint32_t i = ch * 64u + lane;
+    const FrNodes nd = fr_load_nodes(s_word, s_xyz, i, n, nby, lane, s_cin, ch, true);
+    if (!nd.live)
+      continue;
+    unsigned long long M[4];
+    uint32_t Q[4];
+    {
+      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(rowT + static_cast<size_t>(nd.row) * 4);
+      const ulonglong2 t0 = src[0], t1 = src[1];
+      const uint4 qq = *reinterpret_cast<const uint4*>(rowQ + static_cast<size_t>(nd.row) * 4);
+      M[0] = fr_excl16(t0.x) + nd.A[0] - nd.P[0];
+      M[1] = fr_excl16(t0.y) + nd.A[1] - nd.P[1];
+      M[2] = fr_excl16(t1.x) + nd.A[2] - nd.P[2];
+      M[3] = fr_excl16(t1.y) + nd.A[3] - nd.P[3];
+      Q[0] = qq.x, Q[1] = qq.y, Q[2] = qq.z, Q[3] = qq.w;
+    }
+    const int bx = nd.xyz & 1023u, by = (nd.xyz >> 10) & 1023u, bz = nd.xyz >> 20;
+    unsigned long long w = nd.W;
+    bool first = true;
+    while (w)
+    {
+      const int p = __ffsll(static_cast<long long>(w)) - 1;
+      w &= w - 1;
+      const int zz = p >> 4, yy = (p >> 2) & 3, xx = p & 3;
+      const unsigned long long Mz = zz == 0 ? M[0] : zz == 1 ? M[1] : zz == 2 ? M[2] : M[3];
+      const uint32_t Qz = zz == 0 ? Q[0] : zz == 1 ? Q[1] : zz == 2 ? Q[2] : Q[3];
+      const uint32_t nib = static_cast<uint32_t>(nd.W >> (p & ~3)) & 0xfu;
+      const uint32_t rank = Qz + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
+      const int k0 = 4 * bx + xx, k1 = 4 * by + yy, k2 = 4 * bz + zz;
+      float4 pt;
+      pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
+      pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
+      pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+      pt.w = __uint_as_float(1u);
+      va.pts[rank] = pt;
+      va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
+      va.bb[rank] = i;
+      if (first)
+        bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
+      first = false;
+    }
+  }
+  __syncthreads();
+  // the extras add to their voxels' weights: rank = row base + channel prefix over the earlier bricks of the row + bits below
+  {
+    const uint32_t ne_l = min(s_ne, static_cast<uint32_t>(FR_EREC));
+    const uint32_t ne_g = sa.counts[2 * FRAME + 1];
+    for (uint32_t e = tid; e < ne_l + ne_g; e += FR_THREADS)
+    {
+      const uint32_t rec = e < ne_l ? s_x2[e] : extras_g[e - ne_l];
+      const uint32_t add = (rec >> 25) + 1u, b = (rec >> 6) & 0x7ffffu, p = rec & 63u;
+      const uint32_t node = fr_node(s_bits64, s_pre, b);
+      const uint32_t xyz = s_xyz[node];
+      const uint32_t r = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
+      const uint32_t zz = p >> 4, yy = (p >> 2) & 3u, xx = p & 3u, sh = p & ~3u;
+      uint32_t acc = 0;
+      for (uint32_t j = fr_node(s_bits64, s_pre, r * nbx); j < node; j++)
+        acc += __popc(static_cast<uint32_t>(s_word[j] >> sh) & 0xfu);
+      const uint32_t nib = static_cast<uint32_t>(s_word[node] >> sh) & 0xfu;
+      const uint32_t rank = rowQ[static_cast<size_t>(r) * 4 + zz] + (static_cast<uint32_t>(fr_excl16(rowT[static_cast<size_t>(r) * 4 + zz]) >> (16 * yy)) & 0xffffu) + acc +
+                            __popc(nib & ((1u << xx) - 1u));
+      atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[rank].w), add);
+    }
+  }
+  __syncthreads();  // the record list is dead: its storage becomes the union-find
+  for (uint32_t i = tid; i < n; i += FR_THREADS)
+    s_par[i] = static_cast<uint16_t>(i);
+  if (tid == 0)
+    h.V = V;
+  __syncthreads();
+  FR_STAMP(6);
+  constexpr int VU = 8;  // voxel records fetched per lane and round in the label pass
+  const uint32_t Vround = (V + 63u) & ~63u;
+  // ---- D: probe, test, union (as k_brick_ccl_lds; the bitmap's prefix is per 64-bit word here).
+  uint32_t* hits = scratch_all + static_cast<size_t>(FRAME) * g.vox_cap * 10u;
+  const uint32_t hcap = g.vox_cap * 5u;
+  uint32_t* opens = hits + hcap;
+  {
+    const int R = s_tab.R, n_rows = s_tab.n_rows;
+    const int sub = tid % LB_LANES;
+    const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
+    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservation below shuffles
+    {
+      const bool live = t < n;
+      const uint32_t xyz = live ? s_xyz[t] : 0u;
+      const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
+      const int lo = max(bx - R, 0), hi = min(bx + R, nbx - 1);
+      constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
+      static_assert(RPL == 2, "the reservation below adds up two rows per lane");
+      uint32_t winv[RPL], rawv[RPL], nbv[RPL];
+      unsigned long long ovv[RPL];
+      int shv[RPL];
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++)
+      {
+        const int row = rr * LB_LANES + sub;
+        winv[rr] = rawv[rr] = nbv[rr] = 0;
+        ovv[rr] = 0;
+        shv[rr] = 0;
+        if (live && row < n_rows)
+        {
+          const unsigned long long q0 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[0];
+          const unsigned long long q1 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[1];
+          const int ddy = static_cast<int8_t>(q0 & 0xffu), ddz = static_cast<int8_t>((q0 >> 8) & 0xffu);
+          const uint32_t rw_valid = static_cast<uint32_t>(q0 >> 16) & 0xffu;
+          ovv[rr] = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
+          const int ny = by + ddy, nz = bz + ddz;
+          if (ny >= 0 && ny < nby && nz < nbz)
+          {
+            const uint32_t firstb = static_cast<uint32_t>((nz * nby + ny) * nbx) + lo;
+            const uint32_t wi = firstb >> 6, sh = firstb & 63u;
+            const unsigned long long w0 = s_bits64[wi], w1 = s_bits64[wi + 1];
+            const uint32_t pre = s_pre[wi];
+            const unsigned long long two = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+            rawv[rr] = static_cast<uint32_t>(two) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick firstb + j
+            shv[rr] = lo - (bx - R);
+            winv[rr] = (rawv[rr] << shv[rr]) & rw_valid;  // bit s: the brick at dx = s - R is occupied and in the half stencil
+            nbv[rr] = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
+          }
+        }
+      }
+      const uint32_t k = __popc(winv[0]) + (RPL > 1 ? __popc(winv[RPL - 1]) : 0u);
+      const uint32_t incl = wave_incl_scan(k);
+      uint32_t base = 0;
+      if (lane == 63 && incl)
+        base = atomicAdd(&s_nh, incl);
+      uint32_t pos = __shfl(base, 63) + incl - k;
+#pragma unroll
+      for (int rr = 0; rr < RPL; rr++)
+      {
+        uint32_t win = winv[rr];
+        while (win)
+        {
+          const int s = __ffs(static_cast<int>(win)) - 1;
+          win &= win - 1;
+          const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * s)) & 0xffu;
+          const uint32_t t2 = nbv[rr] + __popc(rawv[rr] & ((1u << (s - shv[rr])) - 1u));
+          if (pos < hcap)
+            hits[pos] = t | (t2 << 13) | (o << 26);
+          pos++;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nh = s_nh;
+  if (nh > hcap)
+  {
+    if (tid == 0)
+    {
+      h.status = CCL_RETRY_STATUS;
+      h.V = 0;
+    }
+    return;
+  }
+  FR_STAMP(7);
+  constexpr int HU = 8;
+  for (uint32_t i0 = tid * HU; i0 < nh; i0 += FR_THREADS * HU)
+  {
+    uint32_t hv[HU];
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      const uint32_t i = i0 + u;
+      hv[u] = i < nh ? __builtin_nontemporal_load(&hits[i]) : 0xffffffffu;
+    }
+    unsigned long long Aw[HU], Bw[HU], Ms[HU], Mm[HU];
+    uint32_t pa[HU], pb[HU];
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      const bool ok = hv[u] != 0xffffffffu;
+      const uint32_t t = ok ? hv[u] & 8191u : 0u, t2 = ok ? (hv[u] >> 13) & 8191u : 0u, o = ok ? hv[u] >> 26 : 0u;
+      Aw[u] = s_word[t];
+      Bw[u] = s_word[t2];
+      Ms[u] = s_tab.oct[2 * o];
+      Mm[u] = s_tab.oct[2 * o + 1];
+      pa[u] = lb_ld16(s_par, t);
+      pb[u] = lb_ld16(s_par, t2);
+    }
+    uint32_t kind[HU];  // 0 nothing, 1 accepted by the octant matrices, 2 open
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      const uint32_t A8 = lb_oct8(Aw[u]), B8 = lb_oct8(Bw[u]);
+      kind[u] = hv[u] == 0xffffffffu ? 0u : lb_octtest(Ms[u], A8, B8) ? 1u : lb_octtest(Mm[u], A8, B8) ? 2u : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      const unsigned long long m = __ballot(kind[u] == 2u);
+      if (m)
+      {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&s_no, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader);
+        if (kind[u] == 2u)
+          opens[base + __popcll(m & ((1ull << lane) - 1ull))] = hv[u];
+      }
+    }
+    uint32_t cur_t = 0xffffffffu, cur_root = 0;
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+    {
+      if (kind[u] != 1u || pa[u] == pb[u])
+        continue;
+      const uint32_t t = hv[u] & 8191u, t2 = (hv[u] >> 13) & 8191u;
+      cur_root = lb_find(s_par, t == cur_t ? cur_root : t);
+      cur_t = t;
+      uint32_t ra = cur_root, rb = lb_find(s_par, t2);
+      if (ra == rb)
+        continue;
+      cur_root = min(ra, rb);
+      while (ra != rb)
+      {
+        if (ra < rb)
+        {
+          const uint32_t tmp = ra;
+          ra = rb;
+          rb = tmp;
+        }
+        const uint32_t old = lb_cas16(s_par, ra, ra, rb);
+        if (old == ra)
+          break;
+        ra = old;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // flatten, then the open pairs
+    uint32_t roots[LB_MAX / FR_THREADS];
+#pragma unroll
+    for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+    {
+      const uint32_t i = r * FR_THREADS + tid;
+      uint32_t root = i < n ? i : 0u, p;
+      if (i < n)
+        while ((p = lb_ld16(s_par, root)) != root)
+          root = p;
+      roots[r] = root;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+      if (r * FR_THREADS + tid < n)
+        s_par[r * FR_THREADS + tid] = static_cast<uint16_t>(roots[r]);
+    __syncthreads();
+  }
+  const uint32_t no = s_no;
+  FR_STAMP(8);
+  if (prof && tid == 0)
+  {
+    prof[static_cast<size_t>(FRAME) * 32 + 16] = nh;
+    prof[static_cast<size_t>(FRAME) * 32 + 17] = no;
+    prof[static_cast<size_t>(FRAME) * 32 + 18] = n;
+    prof[static_cast<size_t>(FRAME) * 32 + 19] = n_keys;
+    prof[static_cast<size_t>(FRAME) * 32 + 20] = s_ne;
+    prof[static_cast<size_t>(FRAME) * 32 + 21] = V;
+  }
+  constexpr int OU = 8;  // open pairs fetched per lane and round: independent loads in flight
+  for (uint32_t i0 = tid; i0 < no; i0 += FR_THREADS * OU)
+  {
+    uint32_t ov[OU];
+#pragma unroll
+    for (int u = 0; u < OU; u++)
+    {
+      const uint32_t i = i0 + u * FR_THREADS;
+      ov[u] = i < no ? opens[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < OU; u++)
+    {
+      if (ov[u] == 0xffffffffu)
+        continue;
+      const uint32_t hv = ov[u];
+      const uint32_t t = hv & 8191u, t2 = (hv >> 13) & 8191u;
+      uint32_t ra = lb_find(s_par, t), rb = lb_find(s_par, t2);
+      if (ra == rb)
+        continue;
+      const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
+      const int bx = xa & 1023u, by = (xa >> 10) & 1023u, bz = xa >> 20;
+      const int ddx = static_cast<int>(xb & 1023u) - bx, ddy = static_cast<int>((xb >> 10) & 1023u) - by, ddz = static_cast<int>(xb >> 20) - bz;
+      if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, ddx, ddy, ddz))
+        continue;
+      ra = lb_find(s_par, ra);
+      rb = lb_find(s_par, rb);
+      while (ra != rb)
+      {
+        if (ra < rb)
+        {
+          const uint32_t tmp = ra;
+          ra = rb;
+          rb = tmp;
+        }
+        const uint32_t old = lb_cas16(s_par, ra, ra, rb);
+        if (old == ra)
+          break;
+        ra = old;
+      }
+    }
+  }
+  __syncthreads();
+  FR_STAMP(9);
+  // ---- E: component minima: the smallest voxel rank of a component is the first voxel of one of its bricks
+  uint32_t my_root[LB_MAX / FR_THREADS], my_min[LB_MAX / FR_THREADS];
+  unsigned long long my_w[LB_MAX / FR_THREADS];
+#pragma unroll
+  for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+  {
+    const uint32_t i = r * FR_THREADS + tid;
+    my_root[r] = 0xffffffffu;
+    my_min[r] = 0xffffffffu;
+    my_w[r] = 0ull;
+    if (i < n)
+    {
+      uint32_t root = i, p;
+      while ((p = lb_ld16(s_par, root)) != root)
+        root = p;
+      my_root[r] = root;
+      my_w[r] = s_word[i];
+      my_min[r] = bmin_g[i];
+    }
+  }
+  __syncthreads();  // roots and words are in registers: flatten the forest, turn the words into the minima
+#pragma unroll
+  for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+  {
+    const uint32_t i = r * FR_THREADS + tid;
+    if (i < n)
+    {
+      s_par[i] = static_cast<uint16_t>(my_root[r]);
+      s_cmin[i] = 0xffffffffu;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+    if (my_root[r] != 0xffffffffu)
+      atomicMin(&s_cmin[my_root[r]], my_min[r]);
+  __syncthreads();
+  // ---- cluster statistics (size, lattice box, close flag) brick by brick, as k_brick_ccl_lds
+  uint16_t* s_cidx = reinterpret_cast<uint16_t*>(s_word + LB_MAX / 2);               // node (root) -> component index
+  uint32_t* st_label = reinterpret_cast<uint32_t*>(s_cidx + LB_MAX);                 // LB_ST_ROWS x {label, count, close, box[6]}
+  uint32_t* st_cnt = st_label + LB_ST_ROWS;
+  uint32_t* st_close = st_cnt + LB_ST_ROWS;
+  int* st_box = reinterpret_cast<int*>(st_close + LB_ST_ROWS);
+  if (tid == 0)
+    s_nh = 0;  // reused: number of components
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+  {
+    const bool is_root = my_root[r] == static_cast<uint32_t>(r * FR_THREADS + tid);
+    const unsigned long long m = __ballot(is_root);
+    if (!m)
+      continue;
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&s_nh, static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, leader);
+    if (is_root)
+    {
+      const uint32_t c = base + __popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t label = s_cmin[my_root[r]];
+      s_cidx[my_root[r]] = static_cast<uint16_t>(min(c, static_cast<uint32_t>(LB_ST_ROWS)));
+      if (c < LB_ST_ROWS)
+      {
+        st_label[c] = label;
+        st_cnt[c] = 0;
+        st_close[c] = 0;
+        for (int a = 0; a < 3; a++)
+        {
+          st_box[6 * c + a] = 0x7fffffff;
+          st_box[6 * c + 3 + a] = static_cast<int>(0x80000000u);
+        }
+      }
+      else
+      {
+        atomicExch(&va.csize[label], 0u);
+        atomicExch(&va.cclose[label], 0u);
+        for (int a = 0; a < 3; a++)
+        {
+          atomicExch(&va.cbox[6 * label + a], 0x7fffffff);
+          atomicExch(&va.cbox[6 * label + 3 + a], static_cast<int>(0x80000000u));
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LB_MAX / FR_THREADS; r++)
+  {
+    const uint32_t i = r * FR_THREADS + tid;
+    if (r * FR_THREADS + (tid & ~63) >= n)  // the whole wave is past the last brick
+      continue;
+    const bool live = i < n;
+    const unsigned long long W = live ? my_w[r] : 1ull;
+    const uint32_t c = live ? s_cidx[my_root[r]] : 0xffffffffu;
+    const uint32_t xyz = live ? s_xyz[i] : 0u;
+    const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
+    unsigned long long t = W | (W >> 16) | (W >> 32) | (W >> 48);
+    uint32_t ox = static_cast<uint32_t>(t) & 0xffffu;
+    ox = (ox | (ox >> 4) | (ox >> 8) | (ox >> 12)) & 0xfu;
+    t = W | (W >> 1);
+    t |= t >> 2;  // bit 4y + 16z: row (y,z) is occupied
+    unsigned long long ty = t | (t >> 16) | (t >> 32) | (t >> 48);
+    const uint32_t oy = (static_cast<uint32_t>(ty) & 1u) | ((static_cast<uint32_t>(ty) >> 3) & 2u) | ((static_cast<uint32_t>(ty) >> 6) & 4u) | ((static_cast<uint32_t>(ty) >> 9) & 8u);
+    const uint32_t oz = ((W & 0xffffull) ? 1u : 0u) | ((W & 0xffff0000ull) ? 2u : 0u) | ((W & 0xffff00000000ull) ? 4u : 0u) | ((W >> 48) ? 8u : 0u);
+    const int lo[3] = {4 * bx + __ffs(static_cast<int>(ox)) - 1, 4 * by + __ffs(static_cast<int>(oy)) - 1, 4 * bz + __ffs(static_cast<int>(oz)) - 1};
+    const int hi[3] = {4 * bx + 31 - __clz(static_cast<int>(ox)), 4 * by + 31 - __clz(static_cast<int>(oy)), 4 * bz + 31 - __clz(static_cast<int>(oz))};
+    const uint32_t cnt = __popcll(W);
+    bool hit = false;
+    if (live && mapclose && !(c < LB_ST_ROWS ? st_close[c] : 0u))
+    {
+      unsigned long long a = W;
+      while (a && !hit)
+      {
+        constexpr int CB = 8;
+        uint64_t Lq[CB];
+        unsigned long long wq[CB];
+#pragma unroll
+        for (int q = 0; q < CB; q++)
+        {
+          Lq[q] = ~0ull;
+          if (!a)
+            continue;
+          const int p = __ffsll(static_cast<long long>(a)) - 1;
+          a &= a - 1;
+          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
+          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
+          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+          const int mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
+          const int my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
+          const int mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
+          if (mx_ >= 0 && mx_ < mg.sx && my_ >= 0 && my_ < mg.sy && mz_ >= 0 && mz_ < mg.sz)
+            Lq[q] = (static_cast<uint64_t>(mz_) * mg.sy + my_) * mg.sx + mx_;
+          else  // a centre outside the map (a point on the far face of the operation area): the clipped stencil sweep
+            for (int rr = 0; rr < n_crows && !hit; rr++)
+              hit = close_row_hit(mg, mapbits, crows[rr], mx_, my_, mz_);
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++)
+          wq[q] = Lq[q] != ~0ull ? mapclose[Lq[q] >> 6] : 0ull;
+#pragma unroll
+        for (int q = 0; q < CB; q++)
+          hit |= Lq[q] != ~0ull && ((wq[q] >> (Lq[q] & 63)) & 1ull);
+      }
+    }
+    {
+      const uint32_t lead = __shfl(c, __ffsll(static_cast<long long>(__ballot(1))) - 1);
+      const bool same = c == lead && c < LB_ST_ROWS;
+      const unsigned long long m_same = __ballot(same);
+      if (__popcll(m_same) >= 8)
+      {
+        uint32_t rc = same ? cnt : 0u;
+        int rlo[3], rhi[3];
+        for (int a = 0; a < 3; a++)
+        {
+          rlo[a] = same ? lo[a] : 0x7fffffff;
+          rhi[a] = same ? hi[a] : static_cast<int>(0x80000000u);
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1)
+        {
+          rc += __shfl_xor(rc, sft);
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+          {
+            rlo[a] = min(rlo[a], __shfl_xor(rlo[a], sft));
+            rhi[a] = max(rhi[a], __shfl_xor(rhi[a], sft));
+          }
+        }
+        const bool any_hit = __ballot(same && hit) != 0ull;
+        if (lane == __ffsll(static_cast<long long>(m_same)) - 1)
+        {
+          atomicAdd(&st_cnt[lead], rc);
+          if (any_hit)
+            st_close[lead] = 1u;
+          for (int a = 0; a < 3; a++)
+          {
+            atomicMin(&st_box[6 * lead + a], rlo[a]);
+            atomicMax(&st_box[6 * lead + 3 + a], rhi[a]);
+          }
+        }
+        if (same)
+          continue;  // folded into the aggregate
+      }
+    }
+    if (!live)
+      continue;
+    if (c < LB_ST_ROWS)
+    {
+      atomicAdd(&st_cnt[c], cnt);
+      if (hit)
+        st_close[c] = 1u;
+      for (int a = 0; a < 3; a++)
+      {
+        atomicMin(&st_box[6 * c + a], lo[a]);
+        atomicMax(&st_box[6 * c + 3 + a], hi[a]);
+      }
+    }
+    else
+    {
+      const uint32_t label = s_cmin[my_root[r]];
+      atomicAdd(&va.csize[label], cnt);
+      if (hit)
+        atomicOr(&va.cclose[label], 1u);
+      for (int a = 0; a < 3; a++)
+      {
+        atomicMin(&va.cbox[6 * label + a], lo[a]);
+        atomicMax(&va.cbox[6 * label + 3 + a], hi[a]);
+      }
+    }
+  }
+  __syncthreads();
+  uint8_t* st_cand = reinterpret_cast<uint8_t*>(st_box + 6 * LB_ST_ROWS);
+  ClusterRec* table = table_all + static_cast<size_t>(FRAME) * g.vox_cap;  // (the hit list that lived here is dead)
+  CandMember* cands = cand_all + static_cast<size_t>(FRAME) * g.vox_cap;
+  auto is_cand = [&](uint32_t close, uint32_t size, const int* box) {
+    int ext_ok = 1;
+    for (int a = 0; a < 3; a++)
+      ext_ok &= (static_cast<float>(box[3 + a] - box[a]) * g.leaf[a] <= up.cand_max_extent);
+    return !close && static_cast<int>(size) >= up.min_points && ext_ok;
+  };
+  {
+    const uint32_t nc = min(s_nh, static_cast<uint32_t>(LB_ST_ROWS));
+    for (uint32_t c = tid; c < nc; c += FR_THREADS)
+    {
+      const uint32_t label = st_label[c];
+      va.csize[label] = st_cnt[c];
+      va.cclose[label] = st_close[c];
+      for (int a = 0; a < 6; a++)
+        va.cbox[6 * label + a] = st_box[6 * c + a];
+      if (write_tables)
+      {
+        const bool cand = is_cand(st_close[c], st_cnt[c], &st_box[6 * c]);
+        st_cand[c] = cand ? 1 : 0;
+        ClusterRec rec;
+        rec.root = label;
+        rec.size = st_cnt[c];
+        for (int a = 0; a < 3; a++)
+        {
+          rec.imin[a] = st_box[6 * c + a];
+          rec.imax[a] = st_box[6 * c + 3 + a];
+        }
+        rec.close = st_close[c];
+        rec.cand = cand ? 1u : 0u;
+        table[atomicAdd(&h.C, 1u)] = rec;
+      }
+    }
+  }
+  __syncthreads();
+  FR_STAMP(10);
+  // ---- labels (+ candidate members): a voxel's brick node was stored with its record
+  for (uint32_t v0 = tid; v0 < Vround; v0 += FR_THREADS * VU)
+  {
+    uint32_t nodev[VU];
+#pragma unroll
+    for (int u = 0; u < VU; u++)
+    {
+      const uint32_t v = v0 + u * FR_THREADS;
+      nodev[u] = v < V ? va.bb[v] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < VU; u++)
+    {
+      const uint32_t v = v0 + u * FR_THREADS;
+      if (v0 + u * FR_THREADS - tid >= Vround)  // block-uniform
+        break;
+      bool cand = false;
+      uint32_t label = 0;
+      if (v < V)
+      {
+        const uint32_t root = s_par[nodev[u]];
+        label = s_cmin[root];
+        labels[v] = label;
+        if (write_tables)
+        {
+          const uint32_t c = s_cidx[root];
+          if (c < LB_ST_ROWS)
+            cand = st_cand[c] != 0;
+          else
+          {
+            int box[6];
+            for (int a = 0; a < 6; a++)
+              box[a] = __hip_atomic_load(&va.cbox[6 * label + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t close = __hip_atomic_load(&va.cclose[label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t size = __hip_atomic_load(&va.csize[label], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cand = is_cand(close, size, box);
+            if (v == label)  // the component's first voxel writes its record
+            {
+              ClusterRec rec;
+              rec.root = label;
+              rec.size = size;
+              for (int a = 0; a < 3; a++)
+              {
+                rec.imin[a] = box[a];
+                rec.imax[a] = box[3 + a];
+              }
+              rec.close = close;
+              rec.cand = cand ? 1u : 0u;
+              table[atomicAdd(&h.C, 1u)] = rec;
+            }
+          }
+        }
+      }
+      if (write_tables)
+      {
+        const unsigned long long m = __ballot(cand);
+        if (m)
+        {
+          const int leader = __ffsll(static_cast<long long>(m)) - 1;
+          uint32_t base = 0;
+          if (lane == leader)
+            base = atomicAdd(&h.n_cand, static_cast<uint32_t>(__popcll(m)));
+          base = __shfl(base, leader);
+          if (cand)
+          {
+            CandMember cm;
+            cm.root = label;
+            cm.v = v;
+            cands[base + __popcll(m & ((1ull << lane) - 1ull))] = cm;
+          }
+        }
+      }
+    }
+  }
+  FR_STAMP(11);
+  if (tid == 0)
+    h.n_bricks = n;
+#undef FR_STAMP
+}
+
+}  // namespace vk

@@ -22,6 +22,7 @@
 #include "kernels_brick.h"
 #include "kernels_brick_lds.h"
 #include "kernels_classify.h"
+#include "kernels_frame.h"
 #include "kernels_cluster.h"
 #include "kernels_raycast.h"
 #include "kernels_slab.h"
@@ -175,6 +176,8 @@ struct Workspace
   CandMember* d_cand = nullptr;
   uint32_t* d_ptrank = nullptr;
   SlabArrays sa{};  // key list / extras of the LDS-slab voxelisation (keys share d_ptrank's storage)
+  FrameScratch fs{};  // row tables of the brick-first frame kernel (kernels_frame.h)
+  bool frame_fused = false;  // k_key2 ran: launch_cluster runs k_frame_lds (voxel records + clustering in one kernel)
   float* d_stage = nullptr;  // F * pt_cap * 5 words: x, y, z, intensity, range of host-resident inputs
   PackedFrame* d_packed = nullptr;
   PackedFrame* h_packed = nullptr;  // pinned
@@ -197,7 +200,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big, fs.rowT, fs.rowQ, fs.bmin};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -263,6 +266,9 @@ struct Workspace
     WS_ALLOC(d_stage, sizeof(float) * 5 * static_cast<size_t>(F) * pt_cap);
     WS_ALLOC(d_packed, sizeof(PackedFrame) * F);
     WS_ALLOC(d_members_big, sizeof(CandMemberX) * static_cast<size_t>(std::max<uint32_t>(vox_cap, 1)));
+    WS_ALLOC(fs.rowT, sizeof(unsigned long long) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
+    WS_ALLOC(fs.rowQ, sizeof(uint32_t) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
+    WS_ALLOC(fs.bmin, sizeof(uint32_t) * LB_MAX * static_cast<size_t>(F));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -809,6 +815,29 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
+  // Batches whose clustering will run inside LDS (plan_lds_ccl): brick-first frame kernel (kernels_frame.h).  One pass over
+  // the input writes the survivors' brick codes; k_frame_lds (launched by launch_cluster) builds the voxel records and
+  // clusters them on the same LDS image.  VOFOD_FRAME_LDS=0 keeps the slab voxeliser + k_brick_ccl_lds of round 1.
+  static const bool frame_on = !(std::getenv("VOFOD_FRAME_LDS") && std::atoi(std::getenv("VOFOD_FRAME_LDS")) == 0);
+  ws.frame_fused = false;
+  if (frame_on && ws.lean_emit && n >= 4 && !want_ptrank)
+  {
+    HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
+    bool packed = true;
+    for (uint32_t f = 0; f < n; f++)
+    {
+      const FrameArgs& a = ws.h_args[f];
+      packed = packed && a.stride == 4 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
+    }
+    const uint32_t gk = std::max(1u, (max_pts + KEY2_THREADS * KEY2_PPT - 1) / (KEY2_THREADS * KEY2_PPT));
+    if (packed)
+      KLAUNCH(h, k_key2<true>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
+    else
+      KLAUNCH(h, k_key2<false>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
+    ws.frame_fused = true;
+    HIPCHK(hipGetLastError());
+    return VOFOD_OK;
+  }
   // Lattices of at most SLAB_MAX slabs of 1 Mi cells: the bitmap is built slab by slab in LDS (kernels_slab.h).
   // VOFOD_SLABS=0 keeps the global-atomic kernels (also used for the counted grid, which needs every point's rank).
   static const bool slabs_on = !(std::getenv("VOFOD_SLABS") && std::atoi(std::getenv("VOFOD_SLABS")) == 0);
@@ -1033,7 +1062,53 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       ws.lean_emit = false;
       unsigned long long*& d_prof = h->d_prof_ccl;
       if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 16 * 4096));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 32 * 4096));
+      if (ws.frame_fused)
+      {
+        ws.frame_fused = false;
+        KLAUNCH(h, k_frame_lds, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose,
+                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof);
+        ws.finalize_fused = up_tables && mapclose;
+        if (d_prof)
+        {
+          // VOFOD_LDS_PROF=1 (diagnostics): phase durations from the 100 MHz wall clock
+          std::vector<unsigned long long> t(32 * n);
+          HIPCHK(hipStreamSynchronize(h->stream));
+          HIPCHK(hipMemcpy(t.data(), d_prof, sizeof(unsigned long long) * 32 * n, hipMemcpyDeviceToHost));
+          static const char* names[11] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit+extras", "probe", "octant+union", "flatten", "exact", "minima+stats"};
+          std::vector<std::pair<double, uint32_t>> byd;
+          unsigned long long t0 = ~0ull, t1 = 0;
+          for (uint32_t f = 0; f < n; f++)
+          {
+            if (!t[32 * f + 11])
+              continue;
+            byd.push_back({(t[32 * f + 11] - t[32 * f]) * 0.01, f});
+            t0 = std::min(t0, t[32 * f]);
+            t1 = std::max(t1, t[32 * f + 11]);
+          }
+          std::sort(byd.begin(), byd.end());
+          double mean = 0;
+          for (auto& b : byd)
+            mean += b.first / byd.size();
+          for (size_t q : {size_t(0), byd.size() / 2, byd.size() - 1})
+          {
+            if (byd.empty())
+              break;
+            const uint32_t f = byd[q].second;
+            std::fprintf(stderr, "[k_frame_lds] frame %u: %.1f us | keys %llu V %llu bricks %llu extras %llu hits %llu open %llu |", f, byd[q].first, t[32 * f + 19], t[32 * f + 21], t[32 * f + 18],
+                         t[32 * f + 20], t[32 * f + 16], t[32 * f + 17]);
+            for (int i = 0; i < 11; i++)
+              std::fprintf(stderr, " %s %.1f", names[i], (t[32 * f + i + 1] - t[32 * f + i]) * 0.01);
+            std::fprintf(stderr, "\n");
+          }
+          if (!byd.empty())
+            std::fprintf(stderr, "[k_frame_lds] %zu workgroups: span %.1f us, mean %.1f us\n", byd.size(), (t1 - t0) * 0.01, mean);
+          HIPCHK(hipMemset(d_prof, 0, sizeof(unsigned long long) * 32 * n));
+        }
+        ws.closefar_fused = mapclose != nullptr;
+        HIPCHK(hipGetLastError());
+        return VOFOD_OK;
+      }
       KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table),
               h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof);
       ws.finalize_fused = up_tables && mapclose;  // cluster table + candidate members written as well (k_finalize's part for read-only batches)
@@ -1447,7 +1522,9 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   up.no_update = no_update;
   // k_slab rewrites the bitmap densely and the brick clustering reads it at set bits only: no need to clean it after use;
   // then the LDS clustering kernel can write the cluster table and the candidate list itself (nothing left for k_finalize)
-  const bool keep_dirty = ws.slab_bitmap && g.sparse_prefix;
+  const bool frame_path = ws.frame_fused;  // brick-first frame kernel: the global occupancy bitmaps are not touched at all
+  const bool bitmap_was_clean = ws.bitmap_clean;
+  const bool keep_dirty = frame_path || (ws.slab_bitmap && g.sparse_prefix);
   r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr,
                      (keep_dirty && no_update) ? &up : nullptr);
   if (r != VOFOD_OK)
@@ -1474,7 +1551,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // ---- K10 updateVMaps :943-950 + cluster table + candidate members
   if (!ws.finalize_fused)
     KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, keep_dirty ? nullptr : ws.d_bitmaps);
-  ws.bitmap_clean = !keep_dirty;
+  ws.bitmap_clean = frame_path ? bitmap_was_clean : !keep_dirty;
   ws.finalize_fused = false;
   KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
   HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
