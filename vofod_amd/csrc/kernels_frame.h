@@ -46,6 +46,8 @@ struct FrameScratch
   unsigned long long* rowT;  // [F][FR_ROWS_MAX][4]: per brick row, per zz: the four yy channel totals, 16 bits each
   uint32_t* rowQ;            // [F][FR_ROWS_MAX][4]: rank of the first voxel of lattice rows (4 bz + zz, 4 by .. 4 by + 3)
   uint32_t* bmin;            // [F][LB_MAX]: per node, the rank of the brick's first voxel
+  unsigned long long* nodeA; // [F][LB_MAX][4]: per node, per zz: voxels of the earlier bricks of its brick row, per yy channel (16 bits each);
+                             //   bit 63 of [3]: the row began inside the node's 64-node chunk (no carry to add)
 };
 
 // ---- K1-K5a in one pass: brick codes of the surviving points ---------------------------------------------------
@@ -176,43 +178,49 @@ __device__ __forceinline__ uint32_t fr_hsum16(unsigned long long x)
   return static_cast<uint32_t>(x & 0xffffu) + static_cast<uint32_t>((x >> 16) & 0xffffu) + static_cast<uint32_t>((x >> 32) & 0xffffu) + static_cast<uint32_t>(x >> 48);
 }
 
-__device__ __forceinline__ unsigned long long fr_shfl_up64(unsigned long long v, int s)
-{
-  const uint32_t lo = __shfl_up(static_cast<uint32_t>(v), s), hi = __shfl_up(static_cast<uint32_t>(v >> 32), s);
-  return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
-}
-
 __device__ __forceinline__ unsigned long long fr_shfl64(unsigned long long v, int src)
 {
   const uint32_t lo = __shfl(static_cast<uint32_t>(v), src), hi = __shfl(static_cast<uint32_t>(v >> 32), src);
   return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_mov0_64(unsigned long long v)
+{
+  return static_cast<unsigned long long>(dpp_mov0<CTRL, ROW_MASK>(static_cast<uint32_t>(v))) | (static_cast<unsigned long long>(dpp_mov0<CTRL, ROW_MASK>(static_cast<uint32_t>(v >> 32))) << 32);
+}
+
 // Segmented inclusive scan over the wave's lanes: four 64-bit values per lane, a segment starts at every lane whose
 // `head` is set.  Afterwards `head` tells whether a head sits at or before the lane (its segment began inside the wave).
-__device__ __forceinline__ void fr_segscan(unsigned long long v[4], bool& head, int lane)
+// Hillis-Steele steps as DPP moves (VALU only): 1, 2, 4, 8 lanes inside the rows of 16, then lane 15 -> next row, lane 31
+// -> upper half; a lane adds what arrives only while no head lies between (its flag is still clear).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void fr_segstep(unsigned long long v[4], uint32_t& f)
 {
-  int f = head ? 1 : 0;
+  unsigned long long t[4];
 #pragma unroll
-  for (int s = 1; s < 64; s <<= 1)
+  for (int q = 0; q < 4; q++)
+    t[q] = dpp_mov0_64<CTRL, ROW_MASK>(v[q]);
+  const uint32_t ft = dpp_mov0<CTRL, ROW_MASK>(f);
+  if (!f)
   {
-    unsigned long long t[4];
 #pragma unroll
     for (int q = 0; q < 4; q++)
-      t[q] = fr_shfl_up64(v[q], s);
-    const int ft = __shfl_up(f, s);
-    if (lane >= s)
-    {
-      if (!f)
-      {
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          v[q] += t[q];
-      }
-      f |= ft;
-    }
+      v[q] += t[q];
   }
-  head = f != 0;
+  f |= ft;
+}
+
+__device__ __forceinline__ void fr_segscan(unsigned long long v[4], bool& head)
+{
+  uint32_t f = head ? 1u : 0u;
+  fr_segstep<0x111, 0xf>(v, f);
+  fr_segstep<0x112, 0xf>(v, f);
+  fr_segstep<0x114, 0xf>(v, f);
+  fr_segstep<0x118, 0xf>(v, f);
+  fr_segstep<0x142, 0xa>(v, f);
+  fr_segstep<0x143, 0xc>(v, f);
+  head = f != 0u;
 }
 
 // The wave's view of 64 consecutive nodes for the rank scans: channel counts P, their segmented (per brick row)
@@ -258,7 +266,7 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
 #pragma unroll
   for (int zz = 0; zz < 4; zz++)
     o.A[zz] = o.P[zz] = fr_chan(o.W, zz);
-  fr_segscan(o.A, head, lane);
+  fr_segscan(o.A, head);
   o.began_here = head;
   if (with_carry && !head)
   {
@@ -326,13 +334,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __syncthreads();
   const uint32_t* codes = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
   uint32_t* extras_g = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
-  constexpr int KPT = 8;  // consecutive codes per thread and round
+  constexpr int KPT = 16;  // consecutive codes per thread and round: points of one ring that share a voxel / brick are merged in registers
   const bool vec_ok = (reinterpret_cast<uintptr_t>(codes) & 15u) == 0u;
   auto load_codes = [&](uint32_t base, uint32_t c[KPT]) {
     if (vec_ok && base + KPT <= n_keys)
     {
-      const uint4 a = *reinterpret_cast<const uint4*>(codes + base), b = *reinterpret_cast<const uint4*>(codes + base + 4);
-      c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+#pragma unroll
+      for (int q = 0; q < KPT / 4; q++)
+      {
+        const uint4 a = *reinterpret_cast<const uint4*>(codes + base + 4 * q);
+        c[4 * q] = a.x, c[4 * q + 1] = a.y, c[4 * q + 2] = a.z, c[4 * q + 3] = a.w;
+      }
     }
     else
     {
@@ -413,15 +425,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   FR_STAMP(2);
   // ---- 3: occupancy words.  A thread ORs the run of its consecutive codes that share a brick with one LDS atomic per
   // 32-bit half; a code whose bit is set already (inside the run, or in the word as the atomic returns it) is an extra
-  // point of its voxel: record = code | (points - 1) << 25.
+  // point of its voxel: record = code | (points - 1) << 25, appended to the frame's list in global memory (L2).
   {
-    auto push = [&](uint32_t rec) {
-      const uint32_t p = atomicAdd(&s_ne, 1u);
-      if (p < static_cast<uint32_t>(FR_EREC))
-        s_x2[p] = rec;
-      else
-        extras_g[atomicAdd(&sa.counts[2 * FRAME + 1], 1u)] = rec;  // the few records beyond the LDS list
-    };
+    auto push = [&](uint32_t rec) { extras_g[atomicAdd(&s_ne, 1u)] = rec; };  // at most one record per point: the list holds pt_cap entries
     auto flush = [&](uint32_t b, unsigned long long acc) {
       const uint32_t node = fr_node(s_bits64, s_pre, b);
       const uint32_t bz = b / static_cast<uint32_t>(nbx * nby);
@@ -493,10 +499,22 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   }
   __syncthreads();
   FR_STAMP(3);
-  // ---- 4: ranks in key order.  Pass a: per 64-node chunk the sums of its last brick row (rows may span chunks).
+  // ---- 4: ranks in key order.  Pass a: one segmented scan per 64-node chunk; the per-node channel prefixes go to the
+  // frame's scratch in global memory (L2), the sums of the chunk's last brick row to LDS (rows may span chunks).
+  unsigned long long* rowT = fs.rowT + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
+  uint32_t* rowQ = fs.rowQ + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
+  uint32_t* bmin_g = fs.bmin + static_cast<size_t>(FRAME) * LB_MAX;
+  ulonglong2* nodeA = reinterpret_cast<ulonglong2*>(fs.nodeA + static_cast<size_t>(FRAME) * LB_MAX * 4);
+  constexpr unsigned long long FR_BEGAN = 1ull << 63;
   for (uint32_t ch = wave; ch < n_chunks; ch += FR_THREADS / 64)
   {
-    const FrNodes nd = fr_load_nodes(s_word, s_xyz, ch * 64u + lane, n, nby, lane, s_cin, ch, false);
+    const uint32_t i = ch * 64u + lane;
+    const FrNodes nd = fr_load_nodes(s_word, s_xyz, i, n, nby, lane, s_cin, ch, false);
+    if (nd.live)
+    {
+      nodeA[2 * i] = make_ulonglong2(nd.A[0] - nd.P[0], nd.A[1] - nd.P[1]);
+      nodeA[2 * i + 1] = make_ulonglong2(nd.A[2] - nd.P[2], (nd.A[3] - nd.P[3]) | (nd.began_here ? FR_BEGAN : 0ull));
+    }
     if (lane == 63)
     {
 #pragma unroll
@@ -528,7 +546,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         for (int zz = 0; zz < 4; zz++)
           v[zz] = 0ull;
       }
-      fr_segscan(v, hd, lane);
+      fr_segscan(v, hd);
       if (!hd)
       {
 #pragma unroll
@@ -549,18 +567,33 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       s_cin[0][lane] = 0ull;
   }
   __syncthreads();
-  // Pass b: row totals -> global row table (dense index brick row = bz * nby + by; only occupied rows are written / read)
-  unsigned long long* rowT = fs.rowT + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
-  uint32_t* rowQ = fs.rowQ + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
-  uint32_t* bmin_g = fs.bmin + static_cast<size_t>(FRAME) * LB_MAX;
-  for (uint32_t ch = wave; ch < n_chunks; ch += FR_THREADS / 64)
+  // Pass b: the last node of every brick row writes the row's channel totals (dense index brick row = bz * nby + by; only
+  // occupied rows are written / read)
+  for (uint32_t i = tid; i < n; i += FR_THREADS)
   {
-    const FrNodes nd = fr_load_nodes(s_word, s_xyz, ch * 64u + lane, n, nby, lane, s_cin, ch, true);
-    if (nd.tail)
+    const uint32_t xyz = s_xyz[i];
+    const uint32_t row = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
+    bool tail = i + 1 == n;
+    if (!tail)
     {
-      ulonglong2* dst = reinterpret_cast<ulonglong2*>(rowT + static_cast<size_t>(nd.row) * 4);
-      dst[0] = make_ulonglong2(nd.A[0], nd.A[1]);
-      dst[1] = make_ulonglong2(nd.A[2], nd.A[3]);
+      const uint32_t x2 = s_xyz[i + 1];
+      tail = (x2 >> 20) * static_cast<uint32_t>(nby) + ((x2 >> 10) & 1023u) != row;
+    }
+    if (tail)
+    {
+      const ulonglong2 a0 = nodeA[2 * i], a1 = nodeA[2 * i + 1];
+      const unsigned long long W = s_word[i];
+      const bool began = (a1.y & FR_BEGAN) != 0ull;
+      unsigned long long T[4] = {a0.x + fr_chan(W, 0), a0.y + fr_chan(W, 1), a1.x + fr_chan(W, 2), (a1.y & ~FR_BEGAN) + fr_chan(W, 3)};
+      if (!began)
+      {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+          T[zz] += s_cin[i >> 6][zz];
+      }
+      ulonglong2* dst = reinterpret_cast<ulonglong2*>(rowT + static_cast<size_t>(row) * 4);
+      dst[0] = make_ulonglong2(T[0], T[1]);
+      dst[1] = make_ulonglong2(T[2], T[3]);
     }
   }
   __syncthreads();
@@ -623,70 +656,97 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __syncthreads();
   FR_STAMP(5);
   // Pass d: the voxel records leave at their ranks (voxel_grid_weighted.cpp:171-188): centre, weight 1 (+ extras below),
-  // lattice key, node of the brick (for the label pass)
-  for (uint32_t ch = wave; ch < n_chunks; ch += FR_THREADS / 64)
+  // lattice key, node of the brick (for the label pass).  A lane owns a node and walks its 16 channels: lanes next to each
+  // other hold neighbouring bricks of a row, their ranks in one channel are consecutive.
+  for (uint32_t i = tid; i < n; i += FR_THREADS)
   {
-    const uint32_t i = ch * 64u + lane;
-    const FrNodes nd = fr_load_nodes(s_word, s_xyz, i, n, nby, lane, s_cin, ch, true);
-    if (!nd.live)
-      continue;
+    const uint32_t xyz = s_xyz[i];
+    const uint32_t row = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
+    const unsigned long long W = s_word[i];
     unsigned long long M[4];
     uint32_t Q[4];
     {
-      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(rowT + static_cast<size_t>(nd.row) * 4);
+      const ulonglong2 a0 = nodeA[2 * i], a1 = nodeA[2 * i + 1];
+      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(rowT + static_cast<size_t>(row) * 4);
       const ulonglong2 t0 = src[0], t1 = src[1];
-      const uint4 qq = *reinterpret_cast<const uint4*>(rowQ + static_cast<size_t>(nd.row) * 4);
-      M[0] = fr_excl16(t0.x) + nd.A[0] - nd.P[0];
-      M[1] = fr_excl16(t0.y) + nd.A[1] - nd.P[1];
-      M[2] = fr_excl16(t1.x) + nd.A[2] - nd.P[2];
-      M[3] = fr_excl16(t1.y) + nd.A[3] - nd.P[3];
+      const uint4 qq = *reinterpret_cast<const uint4*>(rowQ + static_cast<size_t>(row) * 4);
+      const bool began = (a1.y & FR_BEGAN) != 0ull;
+      M[0] = fr_excl16(t0.x) + a0.x;
+      M[1] = fr_excl16(t0.y) + a0.y;
+      M[2] = fr_excl16(t1.x) + a1.x;
+      M[3] = fr_excl16(t1.y) + (a1.y & ~FR_BEGAN);
+      if (!began)
+      {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+          M[zz] += s_cin[i >> 6][zz];
+      }
       Q[0] = qq.x, Q[1] = qq.y, Q[2] = qq.z, Q[3] = qq.w;
     }
-    const int bx = nd.xyz & 1023u, by = (nd.xyz >> 10) & 1023u, bz = nd.xyz >> 20;
-    unsigned long long w = nd.W;
-    bool first = true;
-    while (w)
+    const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
+    float cx[4], cy[4], cz[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
     {
-      const int p = __ffsll(static_cast<long long>(w)) - 1;
-      w &= w - 1;
-      const int zz = p >> 4, yy = (p >> 2) & 3, xx = p & 3;
-      const unsigned long long Mz = zz == 0 ? M[0] : zz == 1 ? M[1] : zz == 2 ? M[2] : M[3];
-      const uint32_t Qz = zz == 0 ? Q[0] : zz == 1 ? Q[1] : zz == 2 ? Q[2] : Q[3];
-      const uint32_t nib = static_cast<uint32_t>(nd.W >> (p & ~3)) & 0xfu;
-      const uint32_t rank = Qz + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
-      const int k0 = 4 * bx + xx, k1 = 4 * by + yy, k2 = 4 * bz + zz;
-      float4 pt;
-      pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
-      pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
-      pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
-      pt.w = __uint_as_float(1u);
-      va.pts[rank] = pt;
-      va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
-      va.bb[rank] = i;
-      if (first)
-        bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
-      first = false;
+      cx[t] = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + t), 0.5f), g.leaf[0]), h.offset[0]);
+      cy[t] = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + t), 0.5f), g.leaf[1]), h.offset[1]);
+      cz[t] = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + t), 0.5f), g.leaf[2]), h.offset[2]);
+    }
+    const uint32_t key0 = static_cast<uint32_t>(4 * bx + 4 * by * dx + 4 * bz * dxy);
+    bool first = true;
+#pragma unroll
+    for (int zz = 0; zz < 4; zz++)
+    {
+      const uint32_t w16 = static_cast<uint32_t>(W >> (16 * zz)) & 0xffffu;
+      if (!w16)
+        continue;
+#pragma unroll
+      for (int yy = 0; yy < 4; yy++)
+      {
+        const uint32_t nib = (w16 >> (4 * yy)) & 0xfu;
+        if (!nib)
+          continue;
+        uint32_t rank = Q[zz] + (static_cast<uint32_t>(M[zz] >> (16 * yy)) & 0xffffu);
+        if (first)
+          bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
+        first = false;
+#pragma unroll
+        for (int xx = 0; xx < 4; xx++)
+          if ((nib >> xx) & 1u)
+          {
+            float4 pt;
+            pt.x = cx[xx];
+            pt.y = cy[yy];
+            pt.z = cz[zz];
+            pt.w = __uint_as_float(1u);
+            va.pts[rank] = pt;
+            va.key[rank] = key0 + static_cast<uint32_t>(xx + yy * dx + zz * dxy);
+            va.bb[rank] = i;
+            rank++;
+          }
+      }
     }
   }
   __syncthreads();
-  // the extras add to their voxels' weights: rank = row base + channel prefix over the earlier bricks of the row + bits below
+  FR_STAMP(6);
+  // the extras add to their voxels' weights: rank = row base + channel prefix of the earlier bricks of the row + bits below
   {
-    const uint32_t ne_l = min(s_ne, static_cast<uint32_t>(FR_EREC));
-    const uint32_t ne_g = sa.counts[2 * FRAME + 1];
-    for (uint32_t e = tid; e < ne_l + ne_g; e += FR_THREADS)
+    const uint32_t ne = s_ne;
+    for (uint32_t e = tid; e < ne; e += FR_THREADS)
     {
-      const uint32_t rec = e < ne_l ? s_x2[e] : extras_g[e - ne_l];
+      const uint32_t rec = extras_g[e];
       const uint32_t add = (rec >> 25) + 1u, b = (rec >> 6) & 0x7ffffu, p = rec & 63u;
       const uint32_t node = fr_node(s_bits64, s_pre, b);
       const uint32_t xyz = s_xyz[node];
       const uint32_t r = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
-      const uint32_t zz = p >> 4, yy = (p >> 2) & 3u, xx = p & 3u, sh = p & ~3u;
-      uint32_t acc = 0;
-      for (uint32_t j = fr_node(s_bits64, s_pre, r * nbx); j < node; j++)
-        acc += __popc(static_cast<uint32_t>(s_word[j] >> sh) & 0xfu);
-      const uint32_t nib = static_cast<uint32_t>(s_word[node] >> sh) & 0xfu;
-      const uint32_t rank = rowQ[static_cast<size_t>(r) * 4 + zz] + (static_cast<uint32_t>(fr_excl16(rowT[static_cast<size_t>(r) * 4 + zz]) >> (16 * yy)) & 0xffffu) + acc +
-                            __popc(nib & ((1u << xx) - 1u));
+      const uint32_t zz = p >> 4, yy = (p >> 2) & 3u, xx = p & 3u;
+      const unsigned long long* na = fs.nodeA + (static_cast<size_t>(FRAME) * LB_MAX + node) * 4;
+      const unsigned long long az = na[zz], a3 = na[3];
+      unsigned long long Mz = fr_excl16(rowT[static_cast<size_t>(r) * 4 + zz]) + (az & ~FR_BEGAN);
+      if (!(a3 & FR_BEGAN))
+        Mz += s_cin[node >> 6][zz];
+      const uint32_t nib = static_cast<uint32_t>(s_word[node] >> (p & ~3u)) & 0xfu;
+      const uint32_t rank = rowQ[static_cast<size_t>(r) * 4 + zz] + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
       atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[rank].w), add);
     }
   }
@@ -696,58 +756,72 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   if (tid == 0)
     h.V = V;
   __syncthreads();
-  FR_STAMP(6);
+  FR_STAMP(7);
   constexpr int VU = 8;  // voxel records fetched per lane and round in the label pass
   const uint32_t Vround = (V + 63u) & ~63u;
-  // ---- D: probe, test, union (as k_brick_ccl_lds; the bitmap's prefix is per 64-bit word here).
+  // ---- D: probe, test, union (the phases of k_brick_ccl_lds; the bitmap's prefix is per 64-bit word here).
+  // D-a: every (brick, stencil row) reads one window of the brick bitmap; occupied neighbours go to the hit list.
+  // D-b: adjacent-brick hits first (octant matrices, unions), flatten, then the hits two bricks away: most of them now join
+  //      bricks of one component and are dismissed by two LDS reads.  Pairs the octant matrices leave open are collected.
+  // D-c: the open pairs that still join different components are compacted, then tested exactly, one per lane.
   uint32_t* hits = scratch_all + static_cast<size_t>(FRAME) * g.vox_cap * 10u;
   const uint32_t hcap = g.vox_cap * 5u;
   uint32_t* opens = hits + hcap;
   {
     const int R = s_tab.R, n_rows = s_tab.n_rows;
     const int sub = tid % LB_LANES;
+    constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
+    static_assert(RPL == 2, "the reservation below adds up two rows per lane");
+    // a lane serves the same two stencil rows for every brick: their descriptors stay in registers
+    int ddyv[RPL], ddzv[RPL];
+    uint32_t validv[RPL];
+    unsigned long long ovv[RPL];
+#pragma unroll
+    for (int rr = 0; rr < RPL; rr++)
+    {
+      const int row = rr * LB_LANES + sub;
+      ddyv[rr] = ddzv[rr] = 0;
+      validv[rr] = 0;
+      ovv[rr] = 0;
+      if (row < n_rows)
+      {
+        const unsigned long long q0 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[0];
+        const unsigned long long q1 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[1];
+        ddyv[rr] = static_cast<int8_t>(q0 & 0xffu);
+        ddzv[rr] = static_cast<int8_t>((q0 >> 8) & 0xffu);
+        validv[rr] = static_cast<uint32_t>(q0 >> 16) & 0xffu;
+        ovv[rr] = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
+      }
+    }
     const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
-    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservation below shuffles
+    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservation below scans the wave
     {
       const bool live = t < n;
       const uint32_t xyz = live ? s_xyz[t] : 0u;
       const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
       const int lo = max(bx - R, 0), hi = min(bx + R, nbx - 1);
-      constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
-      static_assert(RPL == 2, "the reservation below adds up two rows per lane");
       uint32_t winv[RPL], rawv[RPL], nbv[RPL];
-      unsigned long long ovv[RPL];
       int shv[RPL];
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++)
       {
-        const int row = rr * LB_LANES + sub;
         winv[rr] = rawv[rr] = nbv[rr] = 0;
-        ovv[rr] = 0;
         shv[rr] = 0;
-        if (live && row < n_rows)
+        const int ny = by + ddyv[rr], nz = bz + ddzv[rr];
+        if (live && validv[rr] && ny >= 0 && ny < nby && nz < nbz)
         {
-          const unsigned long long q0 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[0];
-          const unsigned long long q1 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[1];
-          const int ddy = static_cast<int8_t>(q0 & 0xffu), ddz = static_cast<int8_t>((q0 >> 8) & 0xffu);
-          const uint32_t rw_valid = static_cast<uint32_t>(q0 >> 16) & 0xffu;
-          ovv[rr] = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
-          const int ny = by + ddy, nz = bz + ddz;
-          if (ny >= 0 && ny < nby && nz < nbz)
-          {
-            const uint32_t firstb = static_cast<uint32_t>((nz * nby + ny) * nbx) + lo;
-            const uint32_t wi = firstb >> 6, sh = firstb & 63u;
-            const unsigned long long w0 = s_bits64[wi], w1 = s_bits64[wi + 1];
-            const uint32_t pre = s_pre[wi];
-            const unsigned long long two = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
-            rawv[rr] = static_cast<uint32_t>(two) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick firstb + j
-            shv[rr] = lo - (bx - R);
-            winv[rr] = (rawv[rr] << shv[rr]) & rw_valid;  // bit s: the brick at dx = s - R is occupied and in the half stencil
-            nbv[rr] = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
-          }
+          const uint32_t firstb = static_cast<uint32_t>((nz * nby + ny) * nbx) + lo;
+          const uint32_t wi = firstb >> 6, sh = firstb & 63u;
+          const unsigned long long w0 = s_bits64[wi], w1 = s_bits64[wi + 1];
+          const uint32_t pre = s_pre[wi];
+          const unsigned long long two = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+          rawv[rr] = static_cast<uint32_t>(two) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick firstb + j
+          shv[rr] = lo - (bx - R);
+          winv[rr] = (rawv[rr] << shv[rr]) & validv[rr];  // bit s: the brick at dx = s - R is occupied and in the half stencil
+          nbv[rr] = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
         }
       }
-      const uint32_t k = __popc(winv[0]) + (RPL > 1 ? __popc(winv[RPL - 1]) : 0u);
+      const uint32_t k = __popc(winv[0]) + __popc(winv[1]);
       const uint32_t incl = wave_incl_scan(k);
       uint32_t base = 0;
       if (lane == 63 && incl)
@@ -781,84 +855,23 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     }
     return;
   }
-  FR_STAMP(7);
-  constexpr int HU = 8;
-  for (uint32_t i0 = tid * HU; i0 < nh; i0 += FR_THREADS * HU)
-  {
-    uint32_t hv[HU];
-#pragma unroll
-    for (int u = 0; u < HU; u++)
+  FR_STAMP(8);
+  auto link = [&](uint32_t ra, uint32_t rb) {  // hook the larger root under the smaller (labels: smallest member)
+    while (ra != rb)
     {
-      const uint32_t i = i0 + u;
-      hv[u] = i < nh ? __builtin_nontemporal_load(&hits[i]) : 0xffffffffu;
-    }
-    unsigned long long Aw[HU], Bw[HU], Ms[HU], Mm[HU];
-    uint32_t pa[HU], pb[HU];
-#pragma unroll
-    for (int u = 0; u < HU; u++)
-    {
-      const bool ok = hv[u] != 0xffffffffu;
-      const uint32_t t = ok ? hv[u] & 8191u : 0u, t2 = ok ? (hv[u] >> 13) & 8191u : 0u, o = ok ? hv[u] >> 26 : 0u;
-      Aw[u] = s_word[t];
-      Bw[u] = s_word[t2];
-      Ms[u] = s_tab.oct[2 * o];
-      Mm[u] = s_tab.oct[2 * o + 1];
-      pa[u] = lb_ld16(s_par, t);
-      pb[u] = lb_ld16(s_par, t2);
-    }
-    uint32_t kind[HU];  // 0 nothing, 1 accepted by the octant matrices, 2 open
-#pragma unroll
-    for (int u = 0; u < HU; u++)
-    {
-      const uint32_t A8 = lb_oct8(Aw[u]), B8 = lb_oct8(Bw[u]);
-      kind[u] = hv[u] == 0xffffffffu ? 0u : lb_octtest(Ms[u], A8, B8) ? 1u : lb_octtest(Mm[u], A8, B8) ? 2u : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < HU; u++)
-    {
-      const unsigned long long m = __ballot(kind[u] == 2u);
-      if (m)
+      if (ra < rb)
       {
-        const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        uint32_t base = 0;
-        if (lane == leader)
-          base = atomicAdd(&s_no, static_cast<uint32_t>(__popcll(m)));
-        base = __shfl(base, leader);
-        if (kind[u] == 2u)
-          opens[base + __popcll(m & ((1ull << lane) - 1ull))] = hv[u];
+        const uint32_t tmp = ra;
+        ra = rb;
+        rb = tmp;
       }
+      const uint32_t old = lb_cas16(s_par, ra, ra, rb);
+      if (old == ra)
+        break;
+      ra = old;
     }
-    uint32_t cur_t = 0xffffffffu, cur_root = 0;
-#pragma unroll
-    for (int u = 0; u < HU; u++)
-    {
-      if (kind[u] != 1u || pa[u] == pb[u])
-        continue;
-      const uint32_t t = hv[u] & 8191u, t2 = (hv[u] >> 13) & 8191u;
-      cur_root = lb_find(s_par, t == cur_t ? cur_root : t);
-      cur_t = t;
-      uint32_t ra = cur_root, rb = lb_find(s_par, t2);
-      if (ra == rb)
-        continue;
-      cur_root = min(ra, rb);
-      while (ra != rb)
-      {
-        if (ra < rb)
-        {
-          const uint32_t tmp = ra;
-          ra = rb;
-          rb = tmp;
-        }
-        const uint32_t old = lb_cas16(s_par, ra, ra, rb);
-        if (old == ra)
-          break;
-        ra = old;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    // flatten, then the open pairs
+  };
+  auto flatten = [&]() {
     uint32_t roots[LB_MAX / FR_THREADS];
 #pragma unroll
     for (int r = 0; r < LB_MAX / FR_THREADS; r++)
@@ -876,62 +889,146 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       if (r * FR_THREADS + tid < n)
         s_par[r * FR_THREADS + tid] = static_cast<uint16_t>(roots[r]);
     __syncthreads();
-  }
-  const uint32_t no = s_no;
-  FR_STAMP(8);
-  if (prof && tid == 0)
-  {
-    prof[static_cast<size_t>(FRAME) * 32 + 16] = nh;
-    prof[static_cast<size_t>(FRAME) * 32 + 17] = no;
-    prof[static_cast<size_t>(FRAME) * 32 + 18] = n;
-    prof[static_cast<size_t>(FRAME) * 32 + 19] = n_keys;
-    prof[static_cast<size_t>(FRAME) * 32 + 20] = s_ne;
-    prof[static_cast<size_t>(FRAME) * 32 + 21] = V;
-  }
-  constexpr int OU = 8;  // open pairs fetched per lane and round: independent loads in flight
-  for (uint32_t i0 = tid; i0 < no; i0 += FR_THREADS * OU)
-  {
-    uint32_t ov[OU];
-#pragma unroll
-    for (int u = 0; u < OU; u++)
+  };
+  const unsigned long long near_mask = s_tab.near_mask;
+  constexpr int HU = 8;
+  auto hits_pass = [&](const bool far_pass) {
+    // a lane takes HU consecutive hits: they mostly share the brick t (the list is in D-a's order), whose root is then found once
+    for (uint32_t i0 = tid * HU; i0 < nh; i0 += FR_THREADS * HU)
     {
-      const uint32_t i = i0 + u * FR_THREADS;
-      ov[u] = i < no ? opens[i] : 0xffffffffu;
-    }
+      uint32_t hv[HU], pa[HU], pb[HU];
+      bool act[HU];
 #pragma unroll
-    for (int u = 0; u < OU; u++)
-    {
-      if (ov[u] == 0xffffffffu)
-        continue;
-      const uint32_t hv = ov[u];
-      const uint32_t t = hv & 8191u, t2 = (hv >> 13) & 8191u;
-      uint32_t ra = lb_find(s_par, t), rb = lb_find(s_par, t2);
-      if (ra == rb)
-        continue;
-      const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
-      const int bx = xa & 1023u, by = (xa >> 10) & 1023u, bz = xa >> 20;
-      const int ddx = static_cast<int>(xb & 1023u) - bx, ddy = static_cast<int>((xb >> 10) & 1023u) - by, ddz = static_cast<int>(xb >> 20) - bz;
-      if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, ddx, ddy, ddz))
-        continue;
-      ra = lb_find(s_par, ra);
-      rb = lb_find(s_par, rb);
-      while (ra != rb)
+      for (int u = 0; u < HU; u++)
       {
-        if (ra < rb)
+        const uint32_t i = i0 + u;
+        hv[u] = i < nh ? hits[i] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int u = 0; u < HU; u++)
+      {
+        act[u] = hv[u] != 0xffffffffu && (((near_mask >> (hv[u] >> 26)) & 1ull) != 0ull) != far_pass;
+        const uint32_t t = act[u] ? hv[u] & 8191u : 0u, t2 = act[u] ? (hv[u] >> 13) & 8191u : 0u;
+        pa[u] = lb_ld16(s_par, t);
+        pb[u] = lb_ld16(s_par, t2);
+      }
+#pragma unroll
+      for (int u = 0; u < HU; u++)
+        act[u] = act[u] && pa[u] != pb[u];  // equal parents: one component already (after a flatten: equal roots)
+      unsigned long long Aw[HU], Bw[HU], Ms[HU], Mm[HU];
+#pragma unroll
+      for (int u = 0; u < HU; u++)
+      {
+        const uint32_t t = act[u] ? hv[u] & 8191u : 0u, t2 = act[u] ? (hv[u] >> 13) & 8191u : 0u, o = act[u] ? hv[u] >> 26 : 0u;
+        Aw[u] = s_word[t];
+        Bw[u] = s_word[t2];
+        Ms[u] = s_tab.oct[2 * o];
+        Mm[u] = s_tab.oct[2 * o + 1];
+      }
+      uint32_t kind[HU];  // 0 nothing, 1 accepted by the octant matrices, 2 open
+#pragma unroll
+      for (int u = 0; u < HU; u++)
+      {
+        const uint32_t A8 = lb_oct8(Aw[u]), B8 = lb_oct8(Bw[u]);
+        kind[u] = !act[u] ? 0u : lb_octtest(Ms[u], A8, B8) ? 1u : lb_octtest(Mm[u], A8, B8) ? 2u : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < HU; u++)
+      {
+        const unsigned long long m = __ballot(kind[u] == 2u);
+        if (m)
         {
-          const uint32_t tmp = ra;
-          ra = rb;
-          rb = tmp;
+          const int leader = __ffsll(static_cast<long long>(m)) - 1;
+          uint32_t base = 0;
+          if (lane == leader)
+            base = atomicAdd(&s_no, static_cast<uint32_t>(__popcll(m)));
+          base = __shfl(base, leader);
+          if (kind[u] == 2u)
+            opens[base + __popcll(m & ((1ull << lane) - 1ull))] = hv[u];
         }
-        const uint32_t old = lb_cas16(s_par, ra, ra, rb);
-        if (old == ra)
-          break;
-        ra = old;
+      }
+      uint32_t cur_t = 0xffffffffu, cur_root = 0;
+#pragma unroll
+      for (int u = 0; u < HU; u++)
+      {
+        if (kind[u] != 1u)
+          continue;
+        const uint32_t t = hv[u] & 8191u, t2 = (hv[u] >> 13) & 8191u;
+        cur_root = lb_find(s_par, t == cur_t ? cur_root : t);
+        cur_t = t;
+        const uint32_t ra = cur_root, rb = lb_find(s_par, t2);
+        if (ra == rb)
+          continue;
+        cur_root = min(ra, rb);
+        link(ra, rb);
+      }
+    }
+  };
+  hits_pass(false);
+  __syncthreads();
+  flatten();
+  FR_STAMP(9);
+  hits_pass(true);
+  __syncthreads();
+  flatten();
+  const uint32_t no = s_no;
+  FR_STAMP(10);
+  // D-c: keep the open pairs whose ends still sit in different components (roots after the flatten) ...
+  if (tid == 0)
+    s_nh = 0;
+  __syncthreads();
+  {
+    const uint32_t no_round = (no + 63u) & ~63u;
+    for (uint32_t i = tid; i < no_round; i += FR_THREADS)
+    {
+      const uint32_t hv = i < no ? opens[i] : 0xffffffffu;
+      bool keep = false;
+      if (hv != 0xffffffffu)
+        keep = lb_ld16(s_par, hv & 8191u) != lb_ld16(s_par, (hv >> 13) & 8191u);
+      const unsigned long long m = __ballot(keep);
+      if (m)
+      {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&s_nh, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader);
+        if (keep)
+          hits[base + __popcll(m & ((1ull << lane) - 1ull))] = hv;  // the hit list is dead: it holds the survivors
       }
     }
   }
   __syncthreads();
-  FR_STAMP(9);
+  const uint32_t n_surv = s_nh;
+  // ... and test them exactly, one per lane (components merge while this runs: the roots are looked up again)
+  for (uint32_t i = tid; i < n_surv; i += FR_THREADS)
+  {
+    const uint32_t hv = hits[i];
+    const uint32_t t = hv & 8191u, t2 = (hv >> 13) & 8191u;
+    uint32_t ra = lb_find(s_par, t), rb = lb_find(s_par, t2);
+    if (ra == rb)
+      continue;
+    const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
+    const int bx = xa & 1023u, by = (xa >> 10) & 1023u, bz = xa >> 20;
+    const int ddx = static_cast<int>(xb & 1023u) - bx, ddy = static_cast<int>((xb >> 10) & 1023u) - by, ddz = static_cast<int>(xb >> 20) - bz;
+    if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, ddx, ddy, ddz))
+      continue;
+    ra = lb_find(s_par, ra);
+    rb = lb_find(s_par, rb);
+    link(ra, rb);
+  }
+  __syncthreads();
+  FR_STAMP(11);
+  if (prof && tid == 0)
+  {
+    prof[static_cast<size_t>(FRAME) * 32 + 24] = nh;
+    prof[static_cast<size_t>(FRAME) * 32 + 25] = no;
+    prof[static_cast<size_t>(FRAME) * 32 + 26] = n;
+    prof[static_cast<size_t>(FRAME) * 32 + 27] = n_keys;
+    prof[static_cast<size_t>(FRAME) * 32 + 28] = s_ne;
+    prof[static_cast<size_t>(FRAME) * 32 + 29] = V;
+    prof[static_cast<size_t>(FRAME) * 32 + 30] = n_surv;
+  }
   // ---- E: component minima: the smallest voxel rank of a component is the first voxel of one of its bricks
   uint32_t my_root[LB_MAX / FR_THREADS], my_min[LB_MAX / FR_THREADS];
   unsigned long long my_w[LB_MAX / FR_THREADS];
@@ -1182,7 +1279,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     }
   }
   __syncthreads();
-  FR_STAMP(10);
+  FR_STAMP(12);
   // ---- labels (+ candidate members): a voxel's brick node was stored with its record
   for (uint32_t v0 = tid; v0 < Vround; v0 += FR_THREADS * VU)
   {
@@ -1257,7 +1354,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
   }
-  FR_STAMP(11);
+  FR_STAMP(13);
   if (tid == 0)
     h.n_bricks = n;
 #undef FR_STAMP

@@ -310,16 +310,24 @@ __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const Gr
 constexpr int SCAN_WPT = 4;                    // words per thread
 constexpr int SCAN_WPB = 256 * SCAN_WPT;       // words per block
 
+// Data-parallel-primitive moves of the gfx9 VALU (no LDS crossbar involved): lanes without a valid source read 0.
+//   0x110 + s: row_shr:s (shift right by s lanes inside each row of 16), 0x142: row_bcast:15 (lane 15 of every row to the
+//   next row), 0x143: row_bcast:31 (lane 31 to the upper half); row_mask selects the rows that take the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v)
+{
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (every lane must be active)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1)
-  {
-    const uint32_t t = __shfl_up(v, s);
-    if (lane >= s)
-      v += t;
-  }
+  v += dpp_mov0<0x111, 0xf>(v);
+  v += dpp_mov0<0x112, 0xf>(v);
+  v += dpp_mov0<0x114, 0xf>(v);
+  v += dpp_mov0<0x118, 0xf>(v);
+  v += dpp_mov0<0x142, 0xa>(v);
+  v += dpp_mov0<0x143, 0xc>(v);
   return v;
 }
 

@@ -200,7 +200,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big, fs.rowT, fs.rowQ, fs.bmin};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -269,6 +269,7 @@ struct Workspace
     WS_ALLOC(fs.rowT, sizeof(unsigned long long) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.rowQ, sizeof(uint32_t) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.bmin, sizeof(uint32_t) * LB_MAX * static_cast<size_t>(F));
+    WS_ALLOC(fs.nodeA, sizeof(unsigned long long) * 4 * LB_MAX * static_cast<size_t>(F));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -575,6 +576,8 @@ bool build_lds_tables(const EdgeClassifier& classify, const std::vector<BrickOff
       for (auto& x : t.rows[row].o)
         x = -1;
     }
+    if (std::abs(static_cast<int>(offs[o].dx)) <= 1 && std::abs(static_cast<int>(offs[o].dy)) <= 1 && std::abs(static_cast<int>(offs[o].dz)) <= 1)
+      t.near_mask |= 1ull << o;
     const int s = offs[o].dx + R;
     t.rows[row].valid |= static_cast<uint8_t>(1u << s);
     t.rows[row].o[s] = static_cast<int8_t>(o);
@@ -1062,7 +1065,10 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       ws.lean_emit = false;
       unsigned long long*& d_prof = h->d_prof_ccl;
       if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
+      {
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 32 * 4096));
+        HIPCHK(hipMemset(d_prof, 0, sizeof(unsigned long long) * 32 * 4096));
+      }
       if (ws.frame_fused)
       {
         ws.frame_fused = false;
@@ -1075,16 +1081,16 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           std::vector<unsigned long long> t(32 * n);
           HIPCHK(hipStreamSynchronize(h->stream));
           HIPCHK(hipMemcpy(t.data(), d_prof, sizeof(unsigned long long) * 32 * n, hipMemcpyDeviceToHost));
-          static const char* names[11] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit+extras", "probe", "octant+union", "flatten", "exact", "minima+stats"};
+          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "near", "far", "exact", "minima+stats", "labels"};
           std::vector<std::pair<double, uint32_t>> byd;
           unsigned long long t0 = ~0ull, t1 = 0;
           for (uint32_t f = 0; f < n; f++)
           {
-            if (!t[32 * f + 11])
+            if (!t[32 * f + 13])
               continue;
-            byd.push_back({(t[32 * f + 11] - t[32 * f]) * 0.01, f});
+            byd.push_back({(t[32 * f + 13] - t[32 * f]) * 0.01, f});
             t0 = std::min(t0, t[32 * f]);
-            t1 = std::max(t1, t[32 * f + 11]);
+            t1 = std::max(t1, t[32 * f + 13]);
           }
           std::sort(byd.begin(), byd.end());
           double mean = 0;
@@ -1095,9 +1101,9 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
             if (byd.empty())
               break;
             const uint32_t f = byd[q].second;
-            std::fprintf(stderr, "[k_frame_lds] frame %u: %.1f us | keys %llu V %llu bricks %llu extras %llu hits %llu open %llu |", f, byd[q].first, t[32 * f + 19], t[32 * f + 21], t[32 * f + 18],
-                         t[32 * f + 20], t[32 * f + 16], t[32 * f + 17]);
-            for (int i = 0; i < 11; i++)
+            std::fprintf(stderr, "[k_frame_lds] frame %u: %.1f us | keys %llu V %llu bricks %llu extras %llu hits %llu open %llu surviving %llu |", f, byd[q].first, t[32 * f + 27], t[32 * f + 29],
+                         t[32 * f + 26], t[32 * f + 28], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30]);
+            for (int i = 0; i < 13; i++)
               std::fprintf(stderr, " %s %.1f", names[i], (t[32 * f + i + 1] - t[32 * f + i]) * 0.01);
             std::fprintf(stderr, "\n");
           }
