@@ -55,6 +55,7 @@ struct LbTables
   int32_t R;       // reach in bricks along x
   int32_t n_rows;
   unsigned long long near_mask;  // bit o: stencil offset o reaches the adjacent brick only (max(|dx|,|dy|,|dz|) <= 1)
+  unsigned long long axis_mask;  // bit o: face neighbour (|dx| + |dy| + |dz| == 1)
   LbRow rows[LB_MAX_ROWS];
   unsigned long long oct[2 * LB_MAX_OFF];  // per offset: sure8, maybe8 (bit po*8+qo; octant = (x>>1) | (y>>1)<<1 | (z>>1)<<2)
   // The Euclidean predicate on relative voxel offsets (the EdgeClassifier of the host): [dz + RV][dy + RV] bit (dx + RV)

@@ -156,6 +156,13 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key2(const FrameArgs* args, co
 }
 
 // ---- helpers of k_frame_lds ----------------------------------------------------------------------------------------
+// node descriptor: brick coordinates (9 + 9 + 6 bits) and, from pass a of phase 4 on, the brick's 2x2x2 octant occupancy
+__device__ __forceinline__ uint32_t fr_pack(uint32_t bx, uint32_t by, uint32_t bz) { return bx | (by << 9) | (bz << 18); }
+__device__ __forceinline__ int fr_bx(uint32_t d) { return static_cast<int>(d & 511u); }
+__device__ __forceinline__ int fr_by(uint32_t d) { return static_cast<int>((d >> 9) & 511u); }
+__device__ __forceinline__ int fr_bz(uint32_t d) { return static_cast<int>((d >> 18) & 63u); }
+__device__ __forceinline__ uint32_t fr_row(uint32_t d, int nby) { return ((d >> 18) & 63u) * static_cast<uint32_t>(nby) + ((d >> 9) & 511u); }
+
 __device__ __forceinline__ uint32_t fr_node(const unsigned long long* bits64, const uint16_t* pre, uint32_t b)
 {
   return pre[b >> 6] + __popcll(bits64[b >> 6] & ((1ull << (b & 63u)) - 1ull));
@@ -240,15 +247,14 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
   o.live = i < n;
   o.W = o.live ? s_word[i] : 0ull;
   o.xyz = o.live ? s_xyz[i] : 0u;
-  o.row = o.live ? (o.xyz >> 20) * static_cast<uint32_t>(nby) + ((o.xyz >> 10) & 1023u) : 0xffffffffu;
+  o.row = o.live ? fr_row(o.xyz, nby) : 0xffffffffu;
   uint32_t prev = __shfl_up(o.row, 1);
   if (lane == 0)
   {
     prev = 0xfffffffeu;
     if (o.live && i > 0)
     {
-      const uint32_t x = s_xyz[i - 1];
-      prev = (x >> 20) * static_cast<uint32_t>(nby) + ((x >> 10) & 1023u);
+      prev = fr_row(s_xyz[i - 1], nby);
     }
   }
   bool head = o.row != prev;
@@ -258,8 +264,7 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
     next = 0xfffffffeu;
     if (i + 1 < n)
     {
-      const uint32_t x = s_xyz[i + 1];
-      next = (x >> 20) * static_cast<uint32_t>(nby) + ((x >> 10) & 1023u);
+      next = fr_row(s_xyz[i + 1], nby);
     }
   }
   o.tail = o.live && next != o.row;
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ unsigned long long s_cin[FR_CHUNKS + 1][4];  // per chunk: tail sums of its last brick row, then the carry into the chunk
   __shared__ uint32_t s_cflag[FR_CHUNKS + 1];
   __shared__ uint32_t s_wsum[FR_THREADS / 64];
-  __shared__ uint32_t s_n, s_nh, s_no, s_ne;
+  __shared__ uint32_t s_n, s_nh, s_nn, s_nf, s_no, s_ne;
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bits64);
   uint16_t* s_par = reinterpret_cast<uint16_t*>(s_x2);
   const uint32_t FRAME = blockIdx.x;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   if (prof && tid == 0) \
   prof[static_cast<size_t>(FRAME) * 32 + (i)] = wall_clock64()
   FR_STAMP(0);
-  if (static_cast<long long>(nbx) * nby * nbz > static_cast<long long>(LB_BITWORDS) * 32 || nbx > 1023 || nby > 1023 || nbz > FR_MAX_NBZ ||
+  if (static_cast<long long>(nbx) * nby * nbz > static_cast<long long>(LB_BITWORDS) * 32 || nbx > 512 || nby > 512 || nbz > FR_MAX_NBZ ||
       static_cast<uint32_t>(nby) * nbz > FR_ROWS_MAX)
   {
     if (tid == 0)
@@ -329,6 +334,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   {
     s_ne = 0;
     s_nh = 0;
+    s_nn = 0;
+    s_nf = 0;
     s_no = 0;
   }
   __syncthreads();
@@ -354,26 +361,35 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     }
   };
   // ---- 1: the occupied bricks.  Consecutive codes of a thread mostly share their brick: one LDS atomic per run.
-  for (uint32_t base = tid * KPT; base < n_keys; base += FR_THREADS * KPT)
   {
-    uint32_t c[KPT];
-    load_codes(base, c);
-    uint32_t cur = FR_CODE_NONE;
-#pragma unroll
-    for (int u = 0; u < KPT; u++)
+    uint32_t c[KPT], cn[KPT];
+    uint32_t base = tid * KPT;
+    if (base < n_keys)
+      load_codes(base, c);
+    for (; base < n_keys; base += FR_THREADS * KPT)
     {
-      if (c[u] == FR_CODE_NONE)
-        continue;
-      const uint32_t b = c[u] >> 6;
-      if (b != cur)
+      if (base + FR_THREADS * KPT < n_keys)
+        load_codes(base + FR_THREADS * KPT, cn);  // the next round's codes are on their way while this round works
+      uint32_t cur = FR_CODE_NONE;
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
       {
-        if (cur != FR_CODE_NONE)
-          atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
-        cur = b;
+        if (c[u] == FR_CODE_NONE)
+          continue;
+        const uint32_t b = c[u] >> 6;
+        if (b != cur)
+        {
+          if (cur != FR_CODE_NONE)
+            atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+          cur = b;
+        }
       }
+      if (cur != FR_CODE_NONE)
+        atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+        c[u] = cn[u];
     }
-    if (cur != FR_CODE_NONE)
-      atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
   }
   __syncthreads();
   FR_STAMP(1);
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const uint32_t bz = b / static_cast<uint32_t>(nbx * nby);
       const uint32_t brem = b - bz * static_cast<uint32_t>(nbx * nby);
       const uint32_t by = brem / static_cast<uint32_t>(nbx);
-      s_xyz[node] = (brem - by * nbx) | (by << 10) | (bz << 20);  // every run of the brick writes the same value
+      s_xyz[node] = fr_pack(brem - by * nbx, by, bz);  // every run of the brick writes the same value
       uint32_t* w32 = reinterpret_cast<uint32_t*>(&s_word[node]);
       const uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
       if (lo)
@@ -457,10 +473,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         }
       }
     };
-    for (uint32_t base = tid * KPT; base < n_keys; base += FR_THREADS * KPT)
-    {
-      uint32_t c[KPT];
+    uint32_t c[KPT], cn[KPT];
+    uint32_t base = tid * KPT;
+    if (base < n_keys)
       load_codes(base, c);
+    for (; base < n_keys; base += FR_THREADS * KPT)
+    {
+      if (base + FR_THREADS * KPT < n_keys)
+        load_codes(base + FR_THREADS * KPT, cn);
       uint32_t cur = FR_CODE_NONE, last = FR_CODE_NONE, dups = 0;
       unsigned long long acc = 0ull;
 #pragma unroll
@@ -495,6 +515,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         push(last | ((dups - 1u) << 25));
       if (cur != FR_CODE_NONE)
         flush(cur, acc);
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+        c[u] = cn[u];
     }
   }
   __syncthreads();
@@ -512,6 +535,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     const FrNodes nd = fr_load_nodes(s_word, s_xyz, i, n, nby, lane, s_cin, ch, false);
     if (nd.live)
     {
+      s_xyz[i] = nd.xyz | (lb_oct8(nd.W) << 24);  // the word is final: its octant occupancy rides along for phase D
       nodeA[2 * i] = make_ulonglong2(nd.A[0] - nd.P[0], nd.A[1] - nd.P[1]);
       nodeA[2 * i + 1] = make_ulonglong2(nd.A[2] - nd.P[2], (nd.A[3] - nd.P[3]) | (nd.began_here ? FR_BEGAN : 0ull));
     }
@@ -571,14 +595,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   // occupied rows are written / read)
   for (uint32_t i = tid; i < n; i += FR_THREADS)
   {
-    const uint32_t xyz = s_xyz[i];
-    const uint32_t row = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
-    bool tail = i + 1 == n;
-    if (!tail)
-    {
-      const uint32_t x2 = s_xyz[i + 1];
-      tail = (x2 >> 20) * static_cast<uint32_t>(nby) + ((x2 >> 10) & 1023u) != row;
-    }
+    const uint32_t row = fr_row(s_xyz[i], nby);
+    const bool tail = i + 1 == n || fr_row(s_xyz[i + 1], nby) != row;
     if (tail)
     {
       const ulonglong2 a0 = nodeA[2 * i], a1 = nodeA[2 * i + 1];
@@ -656,12 +674,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __syncthreads();
   FR_STAMP(5);
   // Pass d: the voxel records leave at their ranks (voxel_grid_weighted.cpp:171-188): centre, weight 1 (+ extras below),
-  // lattice key, node of the brick (for the label pass).  A lane owns a node and walks its 16 channels: lanes next to each
-  // other hold neighbouring bricks of a row, their ranks in one channel are consecutive.
+  // node of the brick (for the label pass); the lattice key only for the general kernels that may follow (!write_tables).
   for (uint32_t i = tid; i < n; i += FR_THREADS)
   {
     const uint32_t xyz = s_xyz[i];
-    const uint32_t row = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
+    const uint32_t row = fr_row(xyz, nby);
     const unsigned long long W = s_word[i];
     unsigned long long M[4];
     uint32_t Q[4];
@@ -683,71 +700,79 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
       Q[0] = qq.x, Q[1] = qq.y, Q[2] = qq.z, Q[3] = qq.w;
     }
-    const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
-    float cx[4], cy[4], cz[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-    {
-      cx[t] = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + t), 0.5f), g.leaf[0]), h.offset[0]);
-      cy[t] = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + t), 0.5f), g.leaf[1]), h.offset[1]);
-      cz[t] = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + t), 0.5f), g.leaf[2]), h.offset[2]);
-    }
-    const uint32_t key0 = static_cast<uint32_t>(4 * bx + 4 * by * dx + 4 * bz * dxy);
+    const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
+    unsigned long long w = W;
     bool first = true;
-#pragma unroll
-    for (int zz = 0; zz < 4; zz++)
+    while (w)
     {
-      const uint32_t w16 = static_cast<uint32_t>(W >> (16 * zz)) & 0xffffu;
-      if (!w16)
-        continue;
-#pragma unroll
-      for (int yy = 0; yy < 4; yy++)
-      {
-        const uint32_t nib = (w16 >> (4 * yy)) & 0xfu;
-        if (!nib)
-          continue;
-        uint32_t rank = Q[zz] + (static_cast<uint32_t>(M[zz] >> (16 * yy)) & 0xffffu);
-        if (first)
-          bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
-        first = false;
-#pragma unroll
-        for (int xx = 0; xx < 4; xx++)
-          if ((nib >> xx) & 1u)
-          {
-            float4 pt;
-            pt.x = cx[xx];
-            pt.y = cy[yy];
-            pt.z = cz[zz];
-            pt.w = __uint_as_float(1u);
-            va.pts[rank] = pt;
-            va.key[rank] = key0 + static_cast<uint32_t>(xx + yy * dx + zz * dxy);
-            va.bb[rank] = i;
-            rank++;
-          }
-      }
+      const int p = __ffsll(static_cast<long long>(w)) - 1;
+      w &= w - 1;
+      const int zz = p >> 4, yy = (p >> 2) & 3, xx = p & 3;
+      const unsigned long long Mz = zz == 0 ? M[0] : zz == 1 ? M[1] : zz == 2 ? M[2] : M[3];
+      const uint32_t Qz = zz == 0 ? Q[0] : zz == 1 ? Q[1] : zz == 2 ? Q[2] : Q[3];
+      const uint32_t nib = static_cast<uint32_t>(W >> (p & ~3)) & 0xfu;
+      const uint32_t rank = Qz + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
+      const int k0 = 4 * bx + xx, k1 = 4 * by + yy, k2 = 4 * bz + zz;
+      float4 pt;
+      pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
+      pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
+      pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+      pt.w = __uint_as_float(1u);
+      va.pts[rank] = pt;
+      va.bb[rank] = i;
+      if (!write_tables)
+        va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
+      if (first)
+        bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
+      first = false;
     }
   }
   __syncthreads();
   FR_STAMP(6);
-  // the extras add to their voxels' weights: rank = row base + channel prefix of the earlier bricks of the row + bits below
+  // the extras add to their voxels' weights: rank = row base + channel prefix of the earlier bricks of the row + bits below.
+  // Four records per lane and round: their table reads (L2) are in flight together.
   {
     const uint32_t ne = s_ne;
-    for (uint32_t e = tid; e < ne; e += FR_THREADS)
+    constexpr int EU = 4;
+    for (uint32_t e0 = tid; e0 < ne; e0 += FR_THREADS * EU)
     {
-      const uint32_t rec = extras_g[e];
-      const uint32_t add = (rec >> 25) + 1u, b = (rec >> 6) & 0x7ffffu, p = rec & 63u;
-      const uint32_t node = fr_node(s_bits64, s_pre, b);
-      const uint32_t xyz = s_xyz[node];
-      const uint32_t r = (xyz >> 20) * static_cast<uint32_t>(nby) + ((xyz >> 10) & 1023u);
-      const uint32_t zz = p >> 4, yy = (p >> 2) & 3u, xx = p & 3u;
-      const unsigned long long* na = fs.nodeA + (static_cast<size_t>(FRAME) * LB_MAX + node) * 4;
-      const unsigned long long az = na[zz], a3 = na[3];
-      unsigned long long Mz = fr_excl16(rowT[static_cast<size_t>(r) * 4 + zz]) + (az & ~FR_BEGAN);
-      if (!(a3 & FR_BEGAN))
-        Mz += s_cin[node >> 6][zz];
-      const uint32_t nib = static_cast<uint32_t>(s_word[node] >> (p & ~3u)) & 0xfu;
-      const uint32_t rank = rowQ[static_cast<size_t>(r) * 4 + zz] + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
-      atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[rank].w), add);
+      uint32_t rec[EU], node[EU], r[EU];
+#pragma unroll
+      for (int u = 0; u < EU; u++)
+      {
+        const uint32_t e = e0 + u * FR_THREADS;
+        rec[u] = e < ne ? extras_g[e] : FR_CODE_NONE;
+      }
+      unsigned long long az[EU], a3[EU], tz[EU], wv[EU];
+      uint32_t qz[EU];
+#pragma unroll
+      for (int u = 0; u < EU; u++)
+      {
+        const bool ok = rec[u] != FR_CODE_NONE;
+        const uint32_t b = ok ? (rec[u] >> 6) & 0x7ffffu : 0u, zz = (rec[u] >> 4) & 3u;
+        node[u] = ok ? fr_node(s_bits64, s_pre, b) : 0u;
+        r[u] = fr_row(s_xyz[node[u]], nby);
+        const unsigned long long* na = fs.nodeA + (static_cast<size_t>(FRAME) * LB_MAX + node[u]) * 4;
+        az[u] = na[zz];
+        a3[u] = na[3];
+        tz[u] = ok ? rowT[static_cast<size_t>(r[u]) * 4 + zz] : 0ull;
+        qz[u] = ok ? rowQ[static_cast<size_t>(r[u]) * 4 + zz] : 0u;
+        wv[u] = s_word[node[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < EU; u++)
+      {
+        if (rec[u] == FR_CODE_NONE)
+          continue;
+        const uint32_t add = (rec[u] >> 25) + 1u, p = rec[u] & 63u;
+        const uint32_t zz = p >> 4, yy = (p >> 2) & 3u, xx = p & 3u;
+        unsigned long long Mz = fr_excl16(tz[u]) + (az[u] & ~FR_BEGAN);
+        if (!(a3[u] & FR_BEGAN))
+          Mz += s_cin[node[u] >> 6][zz];
+        const uint32_t nib = static_cast<uint32_t>(wv[u] >> (p & ~3u)) & 0xfu;
+        const uint32_t rank = qz[u] + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
+        atomicAdd(reinterpret_cast<uint32_t*>(&va.pts[rank].w), add);
+      }
     }
   }
   __syncthreads();  // the record list is dead: its storage becomes the union-find
@@ -767,21 +792,36 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   uint32_t* hits = scratch_all + static_cast<size_t>(FRAME) * g.vox_cap * 10u;
   const uint32_t hcap = g.vox_cap * 5u;
   uint32_t* opens = hits + hcap;
+  // three hit lists: face neighbours (<= 3 per brick in the half stencil), the other adjacent bricks (<= 10), the rest
+  const uint32_t cap_axis = 3u * n, cap_near = 10u * n;
+  if (hcap < 14u * n)
+  {
+    if (tid == 0)
+    {
+      h.status = CCL_RETRY_STATUS;
+      h.V = 0;
+    }
+    return;
+  }
+  const uint32_t cap_far = hcap - cap_axis - cap_near;
+  uint32_t* hits_near = hits + cap_axis;
+  uint32_t* hits_far = hits_near + cap_near;
   {
     const int R = s_tab.R, n_rows = s_tab.n_rows;
+    const unsigned long long near_mask = s_tab.near_mask, axis_mask = s_tab.axis_mask;
     const int sub = tid % LB_LANES;
     constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
     static_assert(RPL == 2, "the reservation below adds up two rows per lane");
     // a lane serves the same two stencil rows for every brick: their descriptors stay in registers
     int ddyv[RPL], ddzv[RPL];
-    uint32_t validv[RPL];
+    uint32_t validv[RPL], axisv[RPL], nearv[RPL];  // per window slot s (dx = s - R): in the half stencil / face neighbour / adjacent
     unsigned long long ovv[RPL];
 #pragma unroll
     for (int rr = 0; rr < RPL; rr++)
     {
       const int row = rr * LB_LANES + sub;
       ddyv[rr] = ddzv[rr] = 0;
-      validv[rr] = 0;
+      validv[rr] = axisv[rr] = nearv[rr] = 0;
       ovv[rr] = 0;
       if (row < n_rows)
       {
@@ -791,14 +831,21 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         ddzv[rr] = static_cast<int8_t>((q0 >> 8) & 0xffu);
         validv[rr] = static_cast<uint32_t>(q0 >> 16) & 0xffu;
         ovv[rr] = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
+        for (int sl = 0; sl < LB_WIN; sl++)
+          if ((validv[rr] >> sl) & 1u)
+          {
+            const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * sl)) & 0xffu;
+            axisv[rr] |= static_cast<uint32_t>((axis_mask >> o) & 1ull) << sl;
+            nearv[rr] |= static_cast<uint32_t>((near_mask >> o) & 1ull) << sl;
+          }
       }
     }
     const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
-    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservation below scans the wave
+    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservations below scan the wave
     {
       const bool live = t < n;
       const uint32_t xyz = live ? s_xyz[t] : 0u;
-      const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
+      const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
       const int lo = max(bx - R, 0), hi = min(bx + R, nbx - 1);
       uint32_t winv[RPL], rawv[RPL], nbv[RPL];
       int shv[RPL];
@@ -821,32 +868,50 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           nbv[rr] = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
         }
       }
-      const uint32_t k = __popc(winv[0]) + __popc(winv[1]);
-      const uint32_t incl = wave_incl_scan(k);
-      uint32_t base = 0;
-      if (lane == 63 && incl)
-        base = atomicAdd(&s_nh, incl);
-      uint32_t pos = __shfl(base, 63) + incl - k;
+      // one reservation per wave and list
+      const uint32_t kA = __popc(winv[0] & axisv[0]) + __popc(winv[1] & axisv[1]);
+      const uint32_t kN = __popc(winv[0] & nearv[0] & ~axisv[0]) + __popc(winv[1] & nearv[1] & ~axisv[1]);
+      const uint32_t kF = __popc(winv[0] & ~nearv[0]) + __popc(winv[1] & ~nearv[1]);
+      const uint32_t iA = wave_incl_scan(kA), iN = wave_incl_scan(kN), iF = wave_incl_scan(kF);
+      uint32_t bA = 0, bN = 0, bF = 0;
+      if (lane == 63)
+      {
+        if (iA)
+          bA = atomicAdd(&s_nh, iA);
+        if (iN)
+          bN = atomicAdd(&s_nn, iN);
+        if (iF)
+          bF = atomicAdd(&s_nf, iF);
+      }
+      uint32_t pA = __builtin_amdgcn_readlane(bA, 63) + iA - kA, pN = __builtin_amdgcn_readlane(bN, 63) + iN - kN, pF = __builtin_amdgcn_readlane(bF, 63) + iF - kF;
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++)
       {
         uint32_t win = winv[rr];
         while (win)
         {
-          const int s = __ffs(static_cast<int>(win)) - 1;
+          const int sl = __ffs(static_cast<int>(win)) - 1;
           win &= win - 1;
-          const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * s)) & 0xffu;
-          const uint32_t t2 = nbv[rr] + __popc(rawv[rr] & ((1u << (s - shv[rr])) - 1u));
-          if (pos < hcap)
-            hits[pos] = t | (t2 << 13) | (o << 26);
-          pos++;
+          const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * sl)) & 0xffu;
+          const uint32_t t2 = nbv[rr] + __popc(rawv[rr] & ((1u << (sl - shv[rr])) - 1u));
+          const uint32_t hv = t | (t2 << 13) | (o << 26);
+          if ((axisv[rr] >> sl) & 1u)
+            hits[pA++] = hv;
+          else if ((nearv[rr] >> sl) & 1u)
+            hits_near[pN++] = hv;
+          else
+          {
+            if (pF < cap_far)
+              hits_far[pF] = hv;
+            pF++;
+          }
         }
       }
     }
   }
   __syncthreads();
-  const uint32_t nh = s_nh;
-  if (nh > hcap)
+  const uint32_t nh_axis = s_nh, nh_near = s_nn, nh_far = s_nf;
+  if (nh_far > cap_far)
   {
     if (tid == 0)
     {
@@ -890,38 +955,34 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         s_par[r * FR_THREADS + tid] = static_cast<uint16_t>(roots[r]);
     __syncthreads();
   };
-  const unsigned long long near_mask = s_tab.near_mask;
   constexpr int HU = 8;
-  auto hits_pass = [&](const bool far_pass) {
+  auto hits_pass = [&](const uint32_t* __restrict__ list, const uint32_t nh) {
     // a lane takes HU consecutive hits: they mostly share the brick t (the list is in D-a's order), whose root is then found once
     for (uint32_t i0 = tid * HU; i0 < nh; i0 += FR_THREADS * HU)
     {
-      uint32_t hv[HU], pa[HU], pb[HU];
+      uint32_t hv[HU], da[HU], db[HU];
       bool act[HU];
 #pragma unroll
       for (int u = 0; u < HU; u++)
       {
         const uint32_t i = i0 + u;
-        hv[u] = i < nh ? hits[i] : 0xffffffffu;
+        hv[u] = i < nh ? list[i] : 0xffffffffu;
       }
 #pragma unroll
       for (int u = 0; u < HU; u++)
       {
-        act[u] = hv[u] != 0xffffffffu && (((near_mask >> (hv[u] >> 26)) & 1ull) != 0ull) != far_pass;
+        act[u] = hv[u] != 0xffffffffu;
         const uint32_t t = act[u] ? hv[u] & 8191u : 0u, t2 = act[u] ? (hv[u] >> 13) & 8191u : 0u;
-        pa[u] = lb_ld16(s_par, t);
-        pb[u] = lb_ld16(s_par, t2);
+        // equal parents: one component already (after a flatten: equal roots) - nothing to test
+        act[u] = act[u] && lb_ld16(s_par, t) != lb_ld16(s_par, t2);
+        da[u] = s_xyz[t];
+        db[u] = s_xyz[t2];
       }
-#pragma unroll
-      for (int u = 0; u < HU; u++)
-        act[u] = act[u] && pa[u] != pb[u];  // equal parents: one component already (after a flatten: equal roots)
-      unsigned long long Aw[HU], Bw[HU], Ms[HU], Mm[HU];
+      unsigned long long Ms[HU], Mm[HU];
 #pragma unroll
       for (int u = 0; u < HU; u++)
       {
-        const uint32_t t = act[u] ? hv[u] & 8191u : 0u, t2 = act[u] ? (hv[u] >> 13) & 8191u : 0u, o = act[u] ? hv[u] >> 26 : 0u;
-        Aw[u] = s_word[t];
-        Bw[u] = s_word[t2];
+        const uint32_t o = act[u] ? hv[u] >> 26 : 0u;
         Ms[u] = s_tab.oct[2 * o];
         Mm[u] = s_tab.oct[2 * o + 1];
       }
@@ -929,7 +990,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
 #pragma unroll
       for (int u = 0; u < HU; u++)
       {
-        const uint32_t A8 = lb_oct8(Aw[u]), B8 = lb_oct8(Bw[u]);
+        const uint32_t A8 = da[u] >> 24, B8 = db[u] >> 24;
         kind[u] = !act[u] ? 0u : lb_octtest(Ms[u], A8, B8) ? 1u : lb_octtest(Mm[u], A8, B8) ? 2u : 0u;
       }
 #pragma unroll
@@ -964,14 +1025,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
   };
-  hits_pass(false);
+  hits_pass(hits, nh_axis);
   __syncthreads();
   flatten();
   FR_STAMP(9);
-  hits_pass(true);
+  hits_pass(hits_near, nh_near);
+  __syncthreads();
+  flatten();
+  hits_pass(hits_far, nh_far);
   __syncthreads();
   flatten();
   const uint32_t no = s_no;
+  const uint32_t nh = nh_axis + nh_near + nh_far;
   FR_STAMP(10);
   // D-c: keep the open pairs whose ends still sit in different components (roots after the flatten) ...
   if (tid == 0)
@@ -1009,8 +1074,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     if (ra == rb)
       continue;
     const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
-    const int bx = xa & 1023u, by = (xa >> 10) & 1023u, bz = xa >> 20;
-    const int ddx = static_cast<int>(xb & 1023u) - bx, ddy = static_cast<int>((xb >> 10) & 1023u) - by, ddz = static_cast<int>(xb >> 20) - bz;
+    const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
+    const int ddx = fr_bx(xb) - bx, ddy = fr_by(xb) - by, ddz = fr_bz(xb) - bz;
     if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, ddx, ddy, ddz))
       continue;
     ra = lb_find(s_par, ra);
@@ -1126,7 +1191,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     const unsigned long long W = live ? my_w[r] : 1ull;
     const uint32_t c = live ? s_cidx[my_root[r]] : 0xffffffffu;
     const uint32_t xyz = live ? s_xyz[i] : 0u;
-    const int bx = xyz & 1023u, by = (xyz >> 10) & 1023u, bz = xyz >> 20;
+    const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
     unsigned long long t = W | (W >> 16) | (W >> 32) | (W >> 48);
     uint32_t ox = static_cast<uint32_t>(t) & 0xffffu;
     ox = (ox | (ox >> 4) | (ox >> 8) | (ox >> 12)) & 0xfu;

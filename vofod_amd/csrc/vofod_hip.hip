@@ -578,6 +578,8 @@ bool build_lds_tables(const EdgeClassifier& classify, const std::vector<BrickOff
     }
     if (std::abs(static_cast<int>(offs[o].dx)) <= 1 && std::abs(static_cast<int>(offs[o].dy)) <= 1 && std::abs(static_cast<int>(offs[o].dz)) <= 1)
       t.near_mask |= 1ull << o;
+    if (std::abs(static_cast<int>(offs[o].dx)) + std::abs(static_cast<int>(offs[o].dy)) + std::abs(static_cast<int>(offs[o].dz)) == 1)
+      t.axis_mask |= 1ull << o;
     const int s = offs[o].dx + R;
     t.rows[row].valid |= static_cast<uint8_t>(1u << s);
     t.rows[row].o[s] = static_cast<int8_t>(o);
@@ -1081,7 +1083,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           std::vector<unsigned long long> t(32 * n);
           HIPCHK(hipStreamSynchronize(h->stream));
           HIPCHK(hipMemcpy(t.data(), d_prof, sizeof(unsigned long long) * 32 * n, hipMemcpyDeviceToHost));
-          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "near", "far", "exact", "minima+stats", "labels"};
+          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "axis", "near+far", "exact", "minima+stats", "labels"};
           std::vector<std::pair<double, uint32_t>> byd;
           unsigned long long t0 = ~0ull, t1 = 0;
           for (uint32_t f = 0; f < n; f++)
