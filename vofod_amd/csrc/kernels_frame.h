@@ -39,6 +39,8 @@ constexpr int FR_CHUNKS = LB_MAX / 64;    // 64-node chunks of the rank scans
 constexpr int FR_MAX_NBZ = 64;            // brick layers along z
 constexpr uint32_t FR_ROWS_MAX = 8192;    // brick rows (nby * nbz) the per-frame row tables cover
 constexpr uint32_t FR_CODE_NONE = 0xffffffffu;
+constexpr int FR_BB64 = FR_BW64 + 2 + FR_BW64 / 4;  // 64-bit words of the bitmap (+ 2 guard words) followed by its 16-bit prefix array
+constexpr uint32_t FR_CNT_CAP = FR_BB64 * 8;       // per-voxel byte counters that fit the same storage
 
 // per-frame scratch in global memory (L2-resident: touched sparsely)
 struct FrameScratch
@@ -46,6 +48,7 @@ struct FrameScratch
   unsigned long long* rowT;  // [F][FR_ROWS_MAX][4]: per brick row, per zz: the four yy channel totals, 16 bits each
   uint32_t* rowQ;            // [F][FR_ROWS_MAX][4]: rank of the first voxel of lattice rows (4 bz + zz, 4 by .. 4 by + 3)
   uint32_t* bmin;            // [F][LB_MAX]: per node, the rank of the brick's first voxel
+  unsigned long long* bbsave; // [F][FR_BB64]: the brick bitmap + prefix, parked while their LDS holds the per-voxel point counters
   unsigned long long* nodeA; // [F][LB_MAX][4]: per node, per zz: voxels of the earlier bricks of its brick row, per yy channel (16 bits each);
                              //   bit 63 of [3]: the row began inside the node's 64-node chunk (no carry to add)
 };
@@ -288,8 +291,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
                                                          const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,
                                                          CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof)
 {
-  __shared__ __attribute__((aligned(16))) unsigned long long s_bits64[FR_BW64 + 2];  // brick-lattice bitmap, bit = linear brick id
-  __shared__ uint16_t s_pre[FR_BW64];                                                // exclusive popcount prefix per 64-bit word
+  __shared__ __attribute__((aligned(16))) unsigned long long s_bb[FR_BB64];  // brick-lattice bitmap (bit = linear brick id) + exclusive popcount prefix per
+                                                                            // 64-bit word; during the counting / rank phases: one byte counter per voxel
   __shared__ unsigned long long s_word[LB_MAX];                                      // node -> occupancy word; phase E: component minima / statistics
   __shared__ uint32_t s_xyz[LB_MAX];                                                 // node -> brick coordinates, 10 bits each
   __shared__ __attribute__((aligned(8))) uint32_t s_x2[FR_EREC];                     // extras records (phases 3-4), then the 16-bit union-find
@@ -298,7 +301,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint32_t s_cflag[FR_CHUNKS + 1];
   __shared__ uint32_t s_wsum[FR_THREADS / 64];
   __shared__ uint32_t s_n, s_nh, s_nn, s_nf, s_no, s_ne;
+  unsigned long long* s_bits64 = s_bb;
+  uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
+  uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bits64);
+  uint16_t* s_vbase = reinterpret_cast<uint16_t*>(s_x2);  // node -> index of its first voxel in brick order (counting / rank phases)
   uint16_t* s_par = reinterpret_cast<uint16_t*>(s_x2);
   const uint32_t FRAME = blockIdx.x;
   FrameHdr& h = hdrs[FRAME];
@@ -439,38 +446,140 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   const uint32_t n = s_n;
   const uint32_t n_chunks = (n + 63u) >> 6;
   FR_STAMP(2);
-  // ---- 3: occupancy words.  A thread ORs the run of its consecutive codes that share a brick with one LDS atomic per
-  // 32-bit half; a code whose bit is set already (inside the run, or in the word as the atomic returns it) is an extra
-  // point of its voxel: record = code | (points - 1) << 25, appended to the frame's list in global memory (L2).
+  // ---- 3a: occupancy words.  A thread ORs the run of its consecutive codes that share a brick with one LDS atomic per
+  // 32-bit half, and rewrites its codes as node * 64 + bit: the later passes need no bitmap lookup.
+  uint32_t* codes_w = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
   {
-    auto push = [&](uint32_t rec) { extras_g[atomicAdd(&s_ne, 1u)] = rec; };  // at most one record per point: the list holds pt_cap entries
-    auto flush = [&](uint32_t b, unsigned long long acc) {
-      const uint32_t node = fr_node(s_bits64, s_pre, b);
-      const uint32_t bz = b / static_cast<uint32_t>(nbx * nby);
-      const uint32_t brem = b - bz * static_cast<uint32_t>(nbx * nby);
-      const uint32_t by = brem / static_cast<uint32_t>(nbx);
-      s_xyz[node] = fr_pack(brem - by * nbx, by, bz);  // every run of the brick writes the same value
-      uint32_t* w32 = reinterpret_cast<uint32_t*>(&s_word[node]);
-      const uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
-      if (lo)
+    uint32_t c[KPT], cn[KPT];
+    uint32_t base = tid * KPT;
+    if (base < n_keys)
+      load_codes(base, c);
+    for (; base < n_keys; base += FR_THREADS * KPT)
+    {
+      if (base + FR_THREADS * KPT < n_keys)
+        load_codes(base + FR_THREADS * KPT, cn);
+      uint32_t cur = FR_CODE_NONE, cur_node = 0;
+      unsigned long long acc = 0ull;
+      auto flush = [&]() {
+        uint32_t* w32 = reinterpret_cast<uint32_t*>(&s_word[cur_node]);
+        const uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
+        if (lo)
+          atomicOr(&w32[0], lo);
+        if (hi)
+          atomicOr(&w32[1], hi);
+      };
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
       {
-        uint32_t d = atomicOr(&w32[0], lo) & lo;
-        while (d)
+        if (c[u] == FR_CODE_NONE)
+          continue;
+        const uint32_t b = c[u] >> 6;
+        if (b != cur)
         {
-          const int bit = __ffs(static_cast<int>(d)) - 1;
-          d &= d - 1;
-          push((b << 6) | static_cast<uint32_t>(bit));
+          if (cur != FR_CODE_NONE)
+            flush();
+          cur = b;
+          cur_node = fr_node(s_bits64, s_pre, b);
+          const uint32_t bz = b / static_cast<uint32_t>(nbx * nby);
+          const uint32_t brem = b - bz * static_cast<uint32_t>(nbx * nby);
+          const uint32_t by = brem / static_cast<uint32_t>(nbx);
+          s_xyz[cur_node] = fr_pack(brem - by * nbx, by, bz);  // every run of the brick writes the same value
+          acc = 0ull;
         }
+        acc |= 1ull << (c[u] & 63u);
+        c[u] = (cur_node << 6) | (c[u] & 63u);
       }
-      if (hi)
+      if (cur != FR_CODE_NONE)
+        flush();
+      if (vec_ok && base + KPT <= n_keys)
       {
-        uint32_t d = atomicOr(&w32[1], hi) & hi;
-        while (d)
-        {
-          const int bit = __ffs(static_cast<int>(d)) - 1;
-          d &= d - 1;
-          push((b << 6) | static_cast<uint32_t>(bit + 32));
-        }
+#pragma unroll
+        for (int q = 0; q < KPT / 4; q++)
+          *reinterpret_cast<uint4*>(codes_w + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < KPT; u++)
+          if (base + u < n_keys)
+            codes_w[base + u] = c[u];
+      }
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+        c[u] = cn[u];
+    }
+  }
+  __syncthreads();
+  FR_STAMP(3);
+  // ---- 3b: weights (voxel_grid_weighted.cpp:181).  The bitmap is parked in global memory; its LDS becomes one byte
+  // counter per voxel, indexed in brick order: first voxel of the node + set bits below.  Consecutive equal codes of a
+  // thread add once.  A counter that would pass 255 is undone and the points go to the frame's record list
+  // (node * 64 + bit | (points - 1) << 25), added to the stored weights after the emission.
+  uint32_t V = 0;
+  {
+    ulonglong2* bsave = reinterpret_cast<ulonglong2*>(fs.bbsave + static_cast<size_t>(FRAME) * FR_BB64);
+    for (int i = tid; i < FR_BB64 / 2; i += FR_THREADS)
+      bsave[i] = reinterpret_cast<const ulonglong2*>(s_bb)[i];
+    constexpr int NPT = LB_MAX / FR_THREADS;  // consecutive nodes per thread
+    uint32_t pc[NPT], sum = 0;
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+      const uint32_t i = tid * NPT + r;
+      pc[r] = i < n ? __popcll(s_word[i]) : 0u;
+      sum += pc[r];
+    }
+    const uint32_t incl = wave_incl_scan(sum);
+    if (lane == 63)
+      s_wsum[wave] = incl;
+    __syncthreads();  // (also: every thread has parked its part of the bitmap)
+    uint32_t run = incl - sum;
+    for (int w = 0; w < FR_THREADS / 64; w++)
+    {
+      const uint32_t x = s_wsum[w];
+      run += w < wave ? x : 0u;
+      V += x;
+    }
+    if (V > g.vox_cap)
+    {
+      if (tid == 0)
+      {
+        h.status = VOFOD_ERR_CAPACITY;  // as k_scan_b
+        h.V = 0;
+      }
+      return;
+    }
+    if (V > FR_CNT_CAP || V > 65535u)
+    {
+      if (tid == 0)
+      {
+        h.status = CCL_RETRY_STATUS;  // more voxels than byte counters: the batch takes the general kernels
+        h.V = 0;
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+      const uint32_t i = tid * NPT + r;
+      if (i < n)
+        s_vbase[i] = static_cast<uint16_t>(run);
+      run += pc[r];
+    }
+    for (uint32_t i = tid; i < (V + 15u) / 16u; i += FR_THREADS)
+      reinterpret_cast<uint4*>(s_bb)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  {
+    auto count = [&](uint32_t code, uint32_t add) {
+      const uint32_t node = code >> 6, bit = code & 63u;
+      const uint32_t idx = s_vbase[node] + __popcll(s_word[node] & ((1ull << bit) - 1ull));
+      const uint32_t sh = 8u * (idx & 3u);
+      const uint32_t old = atomicAdd(&s_cnt32[idx >> 2], add << sh);
+      if (((old >> sh) & 0xffu) + add > 255u)
+      {
+        atomicSub(&s_cnt32[idx >> 2], add << sh);
+        extras_g[atomicAdd(&s_ne, 1u)] = code | ((add - 1u) << 25);  // at most one record per point: the list holds pt_cap entries
       }
     };
     uint32_t c[KPT], cn[KPT];
@@ -481,8 +590,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     {
       if (base + FR_THREADS * KPT < n_keys)
         load_codes(base + FR_THREADS * KPT, cn);
-      uint32_t cur = FR_CODE_NONE, last = FR_CODE_NONE, dups = 0;
-      unsigned long long acc = 0ull;
+      uint32_t last = FR_CODE_NONE, cntl = 0;
 #pragma unroll
       for (int u = 0; u < KPT; u++)
       {
@@ -490,38 +598,23 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           continue;
         if (c[u] == last)
         {
-          dups++;
+          cntl++;
           continue;
         }
-        if (dups)
-          push(last | ((dups - 1u) << 25));
-        dups = 0;
+        if (last != FR_CODE_NONE)
+          count(last, cntl);
         last = c[u];
-        const uint32_t b = c[u] >> 6;
-        if (b != cur)
-        {
-          if (cur != FR_CODE_NONE)
-            flush(cur, acc);
-          cur = b;
-          acc = 0ull;
-        }
-        const unsigned long long m = 1ull << (c[u] & 63u);
-        if (acc & m)
-          push(c[u]);  // the voxel came up earlier in this run (not as the previous code)
-        else
-          acc |= m;
+        cntl = 1;
       }
-      if (dups)
-        push(last | ((dups - 1u) << 25));
-      if (cur != FR_CODE_NONE)
-        flush(cur, acc);
+      if (last != FR_CODE_NONE)
+        count(last, cntl);
 #pragma unroll
       for (int u = 0; u < KPT; u++)
         c[u] = cn[u];
     }
   }
   __syncthreads();
-  FR_STAMP(3);
+  FR_STAMP(14);
   // ---- 4: ranks in key order.  Pass a: one segmented scan per 64-node chunk; the per-node channel prefixes go to the
   // frame's scratch in global memory (L2), the sums of the chunk's last brick row to LDS (rows may span chunks).
   unsigned long long* rowT = fs.rowT + static_cast<size_t>(FRAME) * FR_ROWS_MAX * 4;
@@ -616,9 +709,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   }
   __syncthreads();
   FR_STAMP(4);
-  // Pass c: base rank of every lattice-row group in key order: q = (bz * 4 + zz) * nby + by
-  uint32_t V = 0;
+  // Pass c: base rank of every lattice-row group in key order: q = (bz * 4 + zz) * nby + by (row occupancy from the parked bitmap)
   {
+    const unsigned long long* pk_bits = fs.bbsave + static_cast<size_t>(FRAME) * FR_BB64;
+    const uint16_t* pk_pre = reinterpret_cast<const uint16_t*>(pk_bits + FR_BW64 + 2);
     const uint32_t nq = 4u * static_cast<uint32_t>(nby) * nbz;
     const uint32_t qpt = (nq + FR_THREADS - 1) / FR_THREADS;  // <= 32
     const uint32_t q0 = tid * qpt, q1 = min(q0 + qpt, nq);
@@ -629,8 +723,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       r_out = r;
       zz_out = zz;
       const uint32_t b0 = r * nbx, b1 = b0 + nbx;
-      const uint32_t n0 = fr_node(s_bits64, s_pre, b0);
-      const uint32_t n1 = b1 < nb_total ? fr_node(s_bits64, s_pre, b1) : n;
+      const uint32_t n0 = fr_node(pk_bits, pk_pre, b0);
+      const uint32_t n1 = b1 < nb_total ? fr_node(pk_bits, pk_pre, b1) : n;
       return n1 != n0 ? fr_hsum16(rowT[static_cast<size_t>(r) * 4 + zz]) : 0xffffffffu;  // 0xffffffff: the brick row is empty
     };
     uint32_t sum = 0;
@@ -649,7 +743,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     {
       const uint32_t x = s_wsum[w];
       run += w < wave ? x : 0u;
-      V += x;
     }
     for (uint32_t q = q0; q < q1; q++)
     {
@@ -661,15 +754,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         run += s;
       }
     }
-  }
-  if (V > g.vox_cap)
-  {
-    if (tid == 0)
-    {
-      h.status = VOFOD_ERR_CAPACITY;  // as k_scan_b
-      h.V = 0;
-    }
-    return;
   }
   __syncthreads();
   FR_STAMP(5);
@@ -703,6 +787,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
     unsigned long long w = W;
     bool first = true;
+    const uint8_t* cntp = reinterpret_cast<const uint8_t*>(s_bb) + s_vbase[i];  // the node's voxels in bit order
     while (w)
     {
       const int p = __ffsll(static_cast<long long>(w)) - 1;
@@ -717,7 +802,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
       pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
       pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
-      pt.w = __uint_as_float(1u);
+      pt.w = __uint_as_float(static_cast<uint32_t>(*cntp++));  // points in the voxel (the record list below adds what a byte cannot hold)
       va.pts[rank] = pt;
       va.bb[rank] = i;
       if (!write_tables)
@@ -729,8 +814,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   }
   __syncthreads();
   FR_STAMP(6);
-  // the extras add to their voxels' weights: rank = row base + channel prefix of the earlier bricks of the row + bits below.
-  // Four records per lane and round: their table reads (L2) are in flight together.
+  // the records of byte counters that overflowed (none on LiDAR scans) add to their voxels' weights: rank = row base + channel
+  // prefix of the earlier bricks of the row + bits below.  Four records per lane and round.
   {
     const uint32_t ne = s_ne;
     constexpr int EU = 4;
@@ -749,8 +834,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       for (int u = 0; u < EU; u++)
       {
         const bool ok = rec[u] != FR_CODE_NONE;
-        const uint32_t b = ok ? (rec[u] >> 6) & 0x7ffffu : 0u, zz = (rec[u] >> 4) & 3u;
-        node[u] = ok ? fr_node(s_bits64, s_pre, b) : 0u;
+        const uint32_t zz = (rec[u] >> 4) & 3u;
+        node[u] = ok ? (rec[u] >> 6) & 0x7ffffu : 0u;
         r[u] = fr_row(s_xyz[node[u]], nby);
         const unsigned long long* na = fs.nodeA + (static_cast<size_t>(FRAME) * LB_MAX + node[u]) * 4;
         az[u] = na[zz];
@@ -775,7 +860,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
   }
-  __syncthreads();  // the record list is dead: its storage becomes the union-find
+  __syncthreads();  // counters and voxel bases are dead: the bitmap returns, the bases' storage becomes the union-find
+  {
+    const ulonglong2* bsave = reinterpret_cast<const ulonglong2*>(fs.bbsave + static_cast<size_t>(FRAME) * FR_BB64);
+    for (int i = tid; i < FR_BB64 / 2; i += FR_THREADS)
+      reinterpret_cast<ulonglong2*>(s_bb)[i] = bsave[i];
+  }
   for (uint32_t i = tid; i < n; i += FR_THREADS)
     s_par[i] = static_cast<uint16_t>(i);
   if (tid == 0)
@@ -1365,7 +1455,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       uint32_t label = 0;
       if (v < V)
       {
-        const uint32_t root = s_par[nodev[u]];
+        const uint32_t node = nodev[u];
+        const uint32_t root = s_par[node];
         label = s_cmin[root];
         labels[v] = label;
         if (write_tables)

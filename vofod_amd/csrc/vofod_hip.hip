@@ -200,7 +200,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -270,6 +270,7 @@ struct Workspace
     WS_ALLOC(fs.rowQ, sizeof(uint32_t) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.bmin, sizeof(uint32_t) * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.nodeA, sizeof(unsigned long long) * 4 * LB_MAX * static_cast<size_t>(F));
+    WS_ALLOC(fs.bbsave, sizeof(unsigned long long) * FR_BB64 * static_cast<size_t>(F));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -1083,7 +1084,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           std::vector<unsigned long long> t(32 * n);
           HIPCHK(hipStreamSynchronize(h->stream));
           HIPCHK(hipMemcpy(t.data(), d_prof, sizeof(unsigned long long) * 32 * n, hipMemcpyDeviceToHost));
-          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "axis", "near+far", "exact", "minima+stats", "labels"};
+          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "axis", "near+far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
           std::vector<std::pair<double, uint32_t>> byd;
           unsigned long long t0 = ~0ull, t1 = 0;
           for (uint32_t f = 0; f < n; f++)
@@ -1107,7 +1108,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
                          t[32 * f + 26], t[32 * f + 28], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30]);
             for (int i = 0; i < 13; i++)
               std::fprintf(stderr, " %s %.1f", names[i], (t[32 * f + i + 1] - t[32 * f + i]) * 0.01);
-            std::fprintf(stderr, "\n");
+            std::fprintf(stderr, " (count %.1f of rank-a/b)\n", (t[32 * f + 14] - t[32 * f + 3]) * 0.01);
           }
           if (!byd.empty())
             std::fprintf(stderr, "[k_frame_lds] %zu workgroups: span %.1f us, mean %.1f us\n", byd.size(), (t1 - t0) * 0.01, mean);
