@@ -882,7 +882,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   uint32_t* hits = scratch_all + static_cast<size_t>(FRAME) * g.vox_cap * 10u;
   const uint32_t hcap = g.vox_cap * 5u;
   uint32_t* opens = hits + hcap;
-  // three hit lists: face neighbours (<= 3 per brick in the half stencil), the other adjacent bricks (<= 10), the rest
+  // Adjacent bricks first: face neighbours (<= 3 per brick in the half stencil) and the other adjacent bricks (<= 10) go to
+  // two hit lists.  Bricks two apart are looked at after these have been merged - and then only around the bricks outside
+  // the largest component (D-a2 below): a pair inside one component has nothing left to decide.
   const uint32_t cap_axis = 3u * n, cap_near = 10u * n;
   if (hcap < 14u * n)
   {
@@ -896,39 +898,56 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   const uint32_t cap_far = hcap - cap_axis - cap_near;
   uint32_t* hits_near = hits + cap_axis;
   uint32_t* hits_far = hits_near + cap_near;
-  {
-    const int R = s_tab.R, n_rows = s_tab.n_rows;
+  const int R = s_tab.R, n_rows = s_tab.n_rows;
+  constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
+  static_assert(RPL == 2, "the reservation below adds up two rows per lane");
+  // per stencil row: offsets, and per window slot s (dx = s - R): in the half stencil / face neighbour / adjacent
+  auto load_row = [&](int row, int& ddy, int& ddz, uint32_t& valid, uint32_t& axis, uint32_t& near, unsigned long long& ov) {
+    ddy = ddz = 0;
+    valid = axis = near = 0;
+    ov = 0;
+    if (row >= n_rows)
+      return;
     const unsigned long long near_mask = s_tab.near_mask, axis_mask = s_tab.axis_mask;
+    const unsigned long long q0 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[0];
+    const unsigned long long q1 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[1];
+    ddy = static_cast<int8_t>(q0 & 0xffu);
+    ddz = static_cast<int8_t>((q0 >> 8) & 0xffu);
+    valid = static_cast<uint32_t>(q0 >> 16) & 0xffu;
+    ov = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
+    for (int sl = 0; sl < LB_WIN; sl++)
+      if ((valid >> sl) & 1u)
+      {
+        const uint32_t o = static_cast<uint32_t>(ov >> (8 * sl)) & 0xffu;
+        axis |= static_cast<uint32_t>((axis_mask >> o) & 1ull) << sl;
+        near |= static_cast<uint32_t>((near_mask >> o) & 1ull) << sl;
+      }
+  };
+  // the bricks bx - R .. bx + R of lattice row (ny, nz) as a window: bit s = the brick at dx = s - R is occupied;
+  // nb0 / raw / shw recover the node of a set bit: nb0 + popc(raw & ((1 << (s - shw)) - 1))
+  auto window = [&](int bx, int ny, int nz, uint32_t& raw, uint32_t& nb0, int& shw) -> uint32_t {
+    const int lo = max(bx - R, 0), hi = min(bx + R, nbx - 1);
+    const uint32_t firstb = static_cast<uint32_t>((nz * nby + ny) * nbx) + lo;
+    const uint32_t wi = firstb >> 6, sh = firstb & 63u;
+    const unsigned long long w0 = s_bits64[wi], w1 = s_bits64[wi + 1];
+    const uint32_t pre = s_pre[wi];
+    const unsigned long long two = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+    raw = static_cast<uint32_t>(two) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick firstb + j
+    shw = lo - (bx - R);
+    nb0 = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
+    return raw << shw;
+  };
+  {
     const int sub = tid % LB_LANES;
-    constexpr int RPL = LB_MAX_ROWS / LB_LANES;  // rows per lane
-    static_assert(RPL == 2, "the reservation below adds up two rows per lane");
     // a lane serves the same two stencil rows for every brick: their descriptors stay in registers
     int ddyv[RPL], ddzv[RPL];
-    uint32_t validv[RPL], axisv[RPL], nearv[RPL];  // per window slot s (dx = s - R): in the half stencil / face neighbour / adjacent
+    uint32_t validv[RPL], axisv[RPL], nearv[RPL];
     unsigned long long ovv[RPL];
 #pragma unroll
     for (int rr = 0; rr < RPL; rr++)
     {
-      const int row = rr * LB_LANES + sub;
-      ddyv[rr] = ddzv[rr] = 0;
-      validv[rr] = axisv[rr] = nearv[rr] = 0;
-      ovv[rr] = 0;
-      if (row < n_rows)
-      {
-        const unsigned long long q0 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[0];
-        const unsigned long long q1 = reinterpret_cast<const unsigned long long*>(&s_tab.rows[row])[1];
-        ddyv[rr] = static_cast<int8_t>(q0 & 0xffu);
-        ddzv[rr] = static_cast<int8_t>((q0 >> 8) & 0xffu);
-        validv[rr] = static_cast<uint32_t>(q0 >> 16) & 0xffu;
-        ovv[rr] = (q0 >> 24) | (q1 << 40);  // byte s: stencil index of dx = s - R
-        for (int sl = 0; sl < LB_WIN; sl++)
-          if ((validv[rr] >> sl) & 1u)
-          {
-            const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * sl)) & 0xffu;
-            axisv[rr] |= static_cast<uint32_t>((axis_mask >> o) & 1ull) << sl;
-            nearv[rr] |= static_cast<uint32_t>((near_mask >> o) & 1ull) << sl;
-          }
-      }
+      load_row(rr * LB_LANES + sub, ddyv[rr], ddzv[rr], validv[rr], axisv[rr], nearv[rr], ovv[rr]);
+      validv[rr] &= nearv[rr];  // D-a1: adjacent bricks only
     }
     const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
     for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservations below scan the wave
@@ -936,7 +955,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const bool live = t < n;
       const uint32_t xyz = live ? s_xyz[t] : 0u;
       const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
-      const int lo = max(bx - R, 0), hi = min(bx + R, nbx - 1);
       uint32_t winv[RPL], rawv[RPL], nbv[RPL];
       int shv[RPL];
 #pragma unroll
@@ -946,34 +964,21 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         shv[rr] = 0;
         const int ny = by + ddyv[rr], nz = bz + ddzv[rr];
         if (live && validv[rr] && ny >= 0 && ny < nby && nz < nbz)
-        {
-          const uint32_t firstb = static_cast<uint32_t>((nz * nby + ny) * nbx) + lo;
-          const uint32_t wi = firstb >> 6, sh = firstb & 63u;
-          const unsigned long long w0 = s_bits64[wi], w1 = s_bits64[wi + 1];
-          const uint32_t pre = s_pre[wi];
-          const unsigned long long two = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
-          rawv[rr] = static_cast<uint32_t>(two) & ((1u << (hi - lo + 1)) - 1u);  // bit j: brick firstb + j
-          shv[rr] = lo - (bx - R);
-          winv[rr] = (rawv[rr] << shv[rr]) & validv[rr];  // bit s: the brick at dx = s - R is occupied and in the half stencil
-          nbv[rr] = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
-        }
+          winv[rr] = window(bx, ny, nz, rawv[rr], nbv[rr], shv[rr]) & validv[rr];
       }
       // one reservation per wave and list
       const uint32_t kA = __popc(winv[0] & axisv[0]) + __popc(winv[1] & axisv[1]);
-      const uint32_t kN = __popc(winv[0] & nearv[0] & ~axisv[0]) + __popc(winv[1] & nearv[1] & ~axisv[1]);
-      const uint32_t kF = __popc(winv[0] & ~nearv[0]) + __popc(winv[1] & ~nearv[1]);
-      const uint32_t iA = wave_incl_scan(kA), iN = wave_incl_scan(kN), iF = wave_incl_scan(kF);
-      uint32_t bA = 0, bN = 0, bF = 0;
+      const uint32_t kN = __popc(winv[0] & ~axisv[0]) + __popc(winv[1] & ~axisv[1]);
+      const uint32_t iA = wave_incl_scan(kA), iN = wave_incl_scan(kN);
+      uint32_t bA = 0, bN = 0;
       if (lane == 63)
       {
         if (iA)
           bA = atomicAdd(&s_nh, iA);
         if (iN)
           bN = atomicAdd(&s_nn, iN);
-        if (iF)
-          bF = atomicAdd(&s_nf, iF);
       }
-      uint32_t pA = __builtin_amdgcn_readlane(bA, 63) + iA - kA, pN = __builtin_amdgcn_readlane(bN, 63) + iN - kN, pF = __builtin_amdgcn_readlane(bF, 63) + iF - kF;
+      uint32_t pA = __builtin_amdgcn_readlane(bA, 63) + iA - kA, pN = __builtin_amdgcn_readlane(bN, 63) + iN - kN;
 #pragma unroll
       for (int rr = 0; rr < RPL; rr++)
       {
@@ -987,29 +992,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           const uint32_t hv = t | (t2 << 13) | (o << 26);
           if ((axisv[rr] >> sl) & 1u)
             hits[pA++] = hv;
-          else if ((nearv[rr] >> sl) & 1u)
-            hits_near[pN++] = hv;
           else
-          {
-            if (pF < cap_far)
-              hits_far[pF] = hv;
-            pF++;
-          }
+            hits_near[pN++] = hv;
         }
       }
     }
   }
   __syncthreads();
-  const uint32_t nh_axis = s_nh, nh_near = s_nn, nh_far = s_nf;
-  if (nh_far > cap_far)
-  {
-    if (tid == 0)
-    {
-      h.status = CCL_RETRY_STATUS;
-      h.V = 0;
-    }
-    return;
-  }
+  const uint32_t nh_axis = s_nh, nh_near = s_nn;
   FR_STAMP(8);
   auto link = [&](uint32_t ra, uint32_t rb) {  // hook the larger root under the smaller (labels: smallest member)
     while (ra != rb)
@@ -1118,10 +1108,107 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   hits_pass(hits, nh_axis);
   __syncthreads();
   flatten();
-  FR_STAMP(9);
   hits_pass(hits_near, nh_near);
   __syncthreads();
   flatten();
+  FR_STAMP(9);
+  // D-a2: the bricks two apart.  G = the component most bricks belong to (any choice is correct: a pair of different
+  // components has at least one end outside G); the bricks outside G look at their whole stencil, forward and backward,
+  // and keep the neighbours of other components.
+  if (wave == 0)
+  {
+    const uint32_t r = lb_ld16(s_par, static_cast<uint32_t>((static_cast<unsigned long long>(lane) * n) >> 6));
+    uint32_t votes = 0;
+    for (int k = 0; k < 64; k++)
+      votes += __builtin_amdgcn_readlane(r, k) == r ? 1u : 0u;
+    uint32_t best = (votes << 16) | r;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1)
+      best = max(best, static_cast<uint32_t>(__shfl_xor(best, sft)));
+    if (lane == 0)
+    {
+      s_nh = best & 0xffffu;  // G
+      s_nn = 0;               // number of bricks outside G
+    }
+  }
+  __syncthreads();
+  const uint32_t G = s_nh;
+  uint32_t* small = hits;  // (the face-neighbour list is dead)
+  {
+    const uint32_t n_r = (n + 63u) & ~63u;
+    for (uint32_t i = tid; i < n_r; i += FR_THREADS)
+    {
+      const bool out = i < n && lb_ld16(s_par, i) != G;
+      const unsigned long long m = __ballot(out);
+      if (m)
+      {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&s_nn, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader);
+        if (out)
+          small[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n_small = s_nn;
+  {
+    // work item = (brick outside G, stencil row, direction); the row descriptors of an item come from LDS each time
+    const uint32_t items = n_small * 32u;
+    for (uint32_t it = tid; it < items; it += FR_THREADS)
+    {
+      const uint32_t t = small[it >> 5];
+      const int row = (it >> 1) & 15, back = it & 1u;
+      int ddy, ddz;
+      uint32_t valid, axis, near;
+      unsigned long long ov;
+      load_row(row, ddy, ddz, valid, axis, near, ov);
+      uint32_t far = valid & ~near;  // slots of the half stencil two bricks away (forward view)
+      if (!far)
+        continue;
+      if (back)
+      {
+        // the neighbour is the pair's base brick: it sees this brick at (-dx, ddy, ddz), i.e. slot 2R - s
+        uint32_t rev = 0;
+        for (int sl = 0; sl <= 2 * R; sl++)
+          rev |= ((far >> (2 * R - sl)) & 1u) << sl;
+        far = rev;
+      }
+      const uint32_t xyz = s_xyz[t];
+      const int bx = fr_bx(xyz), ny = fr_by(xyz) + (back ? -ddy : ddy), nz = fr_bz(xyz) + (back ? -ddz : ddz);
+      if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
+        continue;
+      uint32_t raw, nb0;
+      int shw;
+      uint32_t win = window(bx, ny, nz, raw, nb0, shw) & far;
+      const uint32_t rt = lb_ld16(s_par, t);
+      while (win)
+      {
+        const int sl = __ffs(static_cast<int>(win)) - 1;
+        win &= win - 1;
+        const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+        if (lb_ld16(s_par, t2) == rt)
+          continue;  // one component already
+        const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
+        const uint32_t pos = atomicAdd(&s_nf, 1u);
+        if (pos < cap_far)
+          hits_far[pos] = back ? (t2 | (t << 13) | (o << 26)) : (t | (t2 << 13) | (o << 26));
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nh_far = s_nf;
+  if (nh_far > cap_far)
+  {
+    if (tid == 0)
+    {
+      h.status = CCL_RETRY_STATUS;
+      h.V = 0;
+    }
+    return;
+  }
   hits_pass(hits_far, nh_far);
   __syncthreads();
   flatten();

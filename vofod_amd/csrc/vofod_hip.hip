@@ -1084,7 +1084,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           std::vector<unsigned long long> t(32 * n);
           HIPCHK(hipStreamSynchronize(h->stream));
           HIPCHK(hipMemcpy(t.data(), d_prof, sizeof(unsigned long long) * 32 * n, hipMemcpyDeviceToHost));
-          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "axis", "near+far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
+          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "adjacent", "far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
           std::vector<std::pair<double, uint32_t>> byd;
           unsigned long long t0 = ~0ull, t1 = 0;
           for (uint32_t f = 0; f < n; f++)
