@@ -41,7 +41,7 @@ def _compare_batches(ref, dev, scans, tfs, chunk=32, clusters_cap=8192):
             except AssertionError as e:
                 raise AssertionError(f"frame {f0 + k}: {e}") from e
         n_det += len(da)
-    return gb, n_det
+    return gb, n_det, db
 
 
 def test_bench_workload_256_frames_os1_128(oracle, hip):
@@ -55,10 +55,14 @@ def test_bench_workload_256_frames_os1_128(oracle, hip):
     frames = synth.bench_frames(scene, "os1-128", F)
     scans = [s.scan for s in frames]
     tfs = np.stack([s.tf for s in frames])
-    gb, n_det = _compare_batches(ref, dev, scans, tfs)
+    gb, n_det, db_full = _compare_batches(ref, dev, scans, tfs)
     assert min(len(g["weighted"]) for g in gb) > 15_000 and max(g["n_input_after_crop"] for g in gb) > 49_152
     # the pipelined form bench.py uses: two tickets in flight give the same detections as the synchronous call
     want = dev.process_batch(scans, tfs)
+    # (the calls without debug output read back the lite slots - candidate clusters only; the debug call above the full tables)
+    np.testing.assert_array_equal(want[0]["n_points"], db_full["n_points"])
+    np.testing.assert_array_equal(want[0]["frame"], db_full["frame"])
+    np.testing.assert_array_equal(want[0]["position"], db_full["position"])
     t0 = dev.batch_submit(scans, tfs)
     t1 = dev.batch_submit(scans, tfs)
     g0, g1 = dev.batch_collect(t0), dev.batch_collect(t1)
@@ -103,7 +107,7 @@ def test_large_os1_128_batch_with_dense_and_empty_frames(oracle, hip):
             scans.append(frames[f % 8].scan)
             tfs.append(frames[f % 8].tf)
     tfs = np.stack(tfs).astype(np.float32)
-    gb, _ = _compare_batches(ref, dev, scans, tfs, clusters_cap=65536)
+    gb, _, _ = _compare_batches(ref, dev, scans, tfs, clusters_cap=65536)
     assert gb[77]["n_input_after_crop"] == 0 and len(gb[77]["weighted"]) == 0
     assert gb[5]["n_input_after_crop"] > 100_000
     assert gb[40]["n_input_after_crop"] - len(gb[40]["weighted"]) > 50_000
@@ -166,7 +170,7 @@ def test_config3_apriori_map_1m_voxels_at_025(oracle, hip):
         np.testing.assert_array_equal(dev.read_map(capi.MAP_VOXELS), ref.read_map(capi.MAP_VOXELS))
         np.testing.assert_array_equal(dev.read_map(capi.MAP_FLAGS), ref.read_map(capi.MAP_FLAGS))
     frames = synth.bench_frames(scene, "os1-128", 8)
-    gb, nb = _compare_batches(ref, dev, [s.scan for s in frames], np.stack([s.tf for s in frames]))
+    gb, nb, _ = _compare_batches(ref, dev, [s.scan for s in frames], np.stack([s.tf for s in frames]))
     # classification ran (far clusters exist and were classified); detections themselves are rare on this scene
     assert sum(int((g["clusters"]["is_close"] == 0).sum()) for g in gb) > 0
     assert gb[0]["background_pts_sufficient"] and gb[0]["sure_background_sufficient"]

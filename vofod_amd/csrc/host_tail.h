@@ -12,6 +12,12 @@
 
 #include "common.h"
 
+#ifdef __HIPCC__
+#define VT_HD __host__ __device__
+#else
+#define VT_HD
+#endif
+
 namespace vt
 {
 
@@ -96,8 +102,8 @@ struct Boxes
   float obb_min[3], obb_max[3], obb_center[3];
 };
 
-// symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations
-inline void eig3(double a[3][3], double w[3], double v[3][3])
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations (host and device: the same IEEE operations in the same order)
+VT_HD inline void eig3(double a[3][3], double w[3], double v[3][3])
 {
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++)
@@ -114,8 +120,8 @@ inline void eig3(double a[3][3], double w[3], double v[3][3])
         if (a[p][q] == 0.0)
           continue;
         const double tau = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        const double t = (tau >= 0.0 ? 1.0 : -1.0) / ((tau < 0.0 ? -tau : tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
         for (int k = 0; k < 3; k++)
         {
           const double x = a[k][p], y = a[k][q];
@@ -141,8 +147,10 @@ inline void eig3(double a[3][3], double w[3], double v[3][3])
 }
 
 // [3P] pcl::MomentOfInertiaEstimation: mean, covariance/n^2, principal axes (major >= middle >= minor,
-// right-handed), AABB and OBB (centre = mean + R*shift).  Members are in ascending index order.
-inline Boxes boxes_of(const MemberSpan& m)
+// right-handed), AABB and OBB (centre = mean + R*shift).  Members in ascending index order; `get(i, p)` fetches the centre
+// of member i.  Host (classification tail, fallback) and device (k_tail_prep) run this very function.
+template <class Get>
+VT_HD inline Boxes boxes_of_n(size_t n, Get get)
 {
   Boxes b;
   float mean[3] = {0, 0, 0};
@@ -151,25 +159,31 @@ inline Boxes boxes_of(const MemberSpan& m)
     b.aabb_min[a] = FLT_MAX;
     b.aabb_max[a] = -FLT_MAX;
   }
-  for (const Member& e : m)
+  for (size_t i = 0; i < n; i++)
+  {
+    float p[3];
+    get(i, p);
     for (int a = 0; a < 3; a++)
     {
-      mean[a] += e.p[a];
-      b.aabb_min[a] = std::min(b.aabb_min[a], e.p[a]);
-      b.aabb_max[a] = std::max(b.aabb_max[a], e.p[a]);
+      mean[a] += p[a];
+      b.aabb_min[a] = p[a] < b.aabb_min[a] ? p[a] : b.aabb_min[a];
+      b.aabb_max[a] = b.aabb_max[a] < p[a] ? p[a] : b.aabb_max[a];
     }
-  const float nf = static_cast<float>(static_cast<unsigned>(m.size()));
+  }
+  const float nf = static_cast<float>(static_cast<unsigned>(n));
   for (int a = 0; a < 3; a++)
     mean[a] /= nf;
   float cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (const Member& e : m)
+  for (size_t i = 0; i < n; i++)
   {
-    const float c[3] = {e.p[0] - mean[0], e.p[1] - mean[1], e.p[2] - mean[2]};
+    float p[3];
+    get(i, p);
+    const float c[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
     for (int r = 0; r < 3; r++)
       for (int q = 0; q < 3; q++)
         cov[r][q] += c[r] * c[q];
   }
-  const float mass = 1.0f / static_cast<float>(m.size() * m.size());
+  const float mass = 1.0f / static_cast<float>(n * n);
   double A[3][3], w[3], V[3][3];
   for (int r = 0; r < 3; r++)
     for (int q = 0; q < 3; q++)
@@ -177,16 +191,28 @@ inline Boxes boxes_of(const MemberSpan& m)
   eig3(A, w, V);
   int ord[3] = {0, 1, 2};
   if (w[ord[0]] < w[ord[1]])
-    std::swap(ord[0], ord[1]);
+  {
+    const int t = ord[0];
+    ord[0] = ord[1];
+    ord[1] = t;
+  }
   if (w[ord[0]] < w[ord[2]])
-    std::swap(ord[0], ord[2]);
+  {
+    const int t = ord[0];
+    ord[0] = ord[2];
+    ord[2] = t;
+  }
   if (w[ord[1]] < w[ord[2]])
-    std::swap(ord[1], ord[2]);
+  {
+    const int t = ord[1];
+    ord[1] = ord[2];
+    ord[2] = t;
+  }
   float ax[3][3];
   for (int k = 0; k < 3; k++)
   {
     float u[3] = {static_cast<float>(V[0][ord[k]]), static_cast<float>(V[1][ord[k]]), static_cast<float>(V[2][ord[k]])};
-    const float nn = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const float nn = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     for (int a = 0; a < 3; a++)
       ax[k][a] = u[a] / nn;
   }
@@ -199,9 +225,11 @@ inline Boxes boxes_of(const MemberSpan& m)
     b.obb_min[k] = FLT_MAX;
     b.obb_max[k] = FLT_MIN;  // PCL initialises the OBB maximum with numeric_limits<float>::min()
   }
-  for (const Member& e : m)
+  for (size_t i = 0; i < n; i++)
   {
-    const float c[3] = {e.p[0] - mean[0], e.p[1] - mean[1], e.p[2] - mean[2]};
+    float p[3];
+    get(i, p);
+    const float c[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
     for (int k = 0; k < 3; k++)
     {
       const float pr = c[0] * ax[k][0] + c[1] * ax[k][1] + c[2] * ax[k][2];
@@ -221,6 +249,15 @@ inline Boxes boxes_of(const MemberSpan& m)
   for (int a = 0; a < 3; a++)
     b.obb_center[a] = mean[a] + (ax[0][a] * shift[0] + ax[1][a] * shift[1] + ax[2][a] * shift[2]);
   return b;
+}
+
+inline Boxes boxes_of(const MemberSpan& m)
+{
+  return boxes_of_n(m.size(), [&](size_t i, float p[3]) {
+    p[0] = m[i].p[0];
+    p[1] = m[i].p[1];
+    p[2] = m[i].p[2];
+  });
 }
 
 // VoxelMap::exploreToGround (voxel_map.cpp:402-488) as a flood fill over a read-back box.  The

@@ -51,8 +51,8 @@ struct ExploreParams
 
 __device__ __forceinline__ uint32_t pack_rel(int dx, int dy, int dz) { return static_cast<uint32_t>((dx + 128) | ((dy + 128) << 8) | ((dz + 128) << 16)); }
 
-// one wave (64 threads) per frame with jobs; job_begin[f]..job_begin[f+1] index that frame's jobs in order
-__global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin,
+// one wave (64 threads) per frame with jobs; job_begin[f]..job_end[f] index that frame's jobs in order
+__global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin, const uint32_t* __restrict__ job_end,
                                                 const int* __restrict__ members, float* __restrict__ map, unsigned long long* __restrict__ overlay_all,
                                                 uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all,
                                                 uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results)
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
   __shared__ uint8_t s_walk[6 * 32];
   const int lane = threadIdx.x;
   const uint32_t slot = blockIdx.x;
-  const uint32_t jb = job_begin[slot], je = job_begin[slot + 1];
+  const uint32_t jb = job_begin[slot], je = job_end[slot];
   if (jb == je)
     return;
   const uint64_t ovl_words = (mg.n + 63) >> 6;

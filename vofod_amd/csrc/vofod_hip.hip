@@ -26,6 +26,7 @@
 #include "kernels_cluster.h"
 #include "kernels_raycast.h"
 #include "kernels_slab.h"
+#include "kernels_tail.h"
 #include "kernels_voxelize.h"
 
 using namespace vk;
@@ -78,6 +79,65 @@ __global__ void k_pack(const GridParams g, const FrameHdr* hdrs, const ClusterRe
     x.z = p.z;
     x.count = __float_as_uint(p.w);
     o.members[t] = x;
+  }
+}
+
+// Read-back of a batch nobody debugs: only what the classification tail consumes - the header, the candidate clusters'
+// records (far, small enough: the others can neither be classified nor detected) and the candidate members.  6.9 KB per
+// frame instead of the 26 KB speculative slot, copied on a stream of its own so that the next batch's chain does not wait for PCIe.
+constexpr uint32_t LITE_C = 16;
+constexpr uint32_t LITE_M = 256;
+struct PackedLite
+{
+  FrameHdr hdr;
+  uint32_t pad[32 - sizeof(FrameHdr) / 4];
+  uint32_t n_recs, n_members, pad2[2];  // counts found on the device (beyond LITE_C / LITE_M: the host fetches the frame's full lists)
+  ClusterRec recs[LITE_C];
+  CandMemberX members[LITE_M];
+};
+
+__global__ __launch_bounds__(256) void k_pack_lite(const GridParams g, const FrameHdr* hdrs, const ClusterRec* table_all, const CandMember* cand_all, VoxelArrays va_all, PackedLite* out)
+{
+  __shared__ uint32_t s_cnt;
+  const uint32_t f = blockIdx.x;
+  const FrameHdr h = hdrs[f];
+  PackedLite& o = out[f];
+  if (threadIdx.x == 0)
+  {
+    o.hdr = h;
+    s_cnt = 0;
+  }
+  __syncthreads();
+  const ClusterRec* table = table_all + static_cast<size_t>(f) * g.vox_cap;
+  for (uint32_t c = threadIdx.x; c < h.C; c += blockDim.x)
+  {
+    const ClusterRec r = table[c];
+    if (r.cand && !r.close)
+    {
+      const uint32_t pos = atomicAdd(&s_cnt, 1u);
+      if (pos < LITE_C)
+        o.recs[pos] = r;
+    }
+  }
+  static_assert(LITE_M <= 256, "one member per thread");
+  if (threadIdx.x < min(h.n_cand, LITE_M))
+  {
+    const CandMember cm = cand_all[static_cast<size_t>(f) * g.vox_cap + threadIdx.x];
+    const float4 p = va_all.pts[static_cast<size_t>(f) * g.vox_cap + cm.v];
+    CandMemberX x;
+    x.root = cm.root;
+    x.v = cm.v;
+    x.x = p.x;
+    x.y = p.y;
+    x.z = p.z;
+    x.count = __float_as_uint(p.w);
+    o.members[threadIdx.x] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    o.n_recs = s_cnt;
+    o.n_members = h.n_cand;
   }
 }
 
@@ -181,6 +241,14 @@ struct Workspace
   float* d_stage = nullptr;  // F * pt_cap * 5 words: x, y, z, intensity, range of host-resident inputs
   PackedFrame* d_packed = nullptr;
   PackedFrame* h_packed = nullptr;  // pinned
+  PackedLite* d_lite = nullptr;
+  PackedLite* h_lite = nullptr;  // pinned
+  bool lite = false;  // the batch in this workspace was read back through the lite slots (no debug output asked for)
+  bool dtail = false;  // ... or its classification tail ran on the device (kernels_tail.h): only detection records come back
+  vtd::TailCluster* d_tailc = nullptr;
+  vtd::FrameDets* d_dets = nullptr;
+  vtd::FrameDets* h_dets = nullptr;  // pinned
+  uint32_t* d_job_be = nullptr;      // [2][F]: first and one-past-last explore job of every frame
   std::vector<FrameArgs> h_args;
   bool bricks_preset = false;  // k_emit already registered the voxels in their bricks (fused brick_set)
   std::vector<vofod_scan> job_scans;  // the submitted batch (re-run when the LDS clustering kernel overflows)
@@ -197,17 +265,27 @@ struct Workspace
   GridParams job_g{};
   std::vector<float> job_tfs;
   hipEvent_t ev_done = nullptr;
+  hipEvent_t ev_packed = nullptr;   // the read-back slots are complete on the chain's stream
+  hipStream_t copy_stream = nullptr;  // device-to-host copy of the slots: the chain's stream goes on with the next batch meanwhile
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
     if (h_packed)
       (void)hipHostFree(h_packed);
+    if (h_lite)
+      (void)hipHostFree(h_lite);
+    if (h_dets)
+      (void)hipHostFree(h_dets);
     if (ev_done)
       (void)hipEventDestroy(ev_done);
+    if (ev_packed)
+      (void)hipEventDestroy(ev_packed);
+    if (copy_stream)
+      (void)hipStreamDestroy(copy_stream);
     *this = Workspace();
   }
 
@@ -265,6 +343,10 @@ struct Workspace
     sa.keys = d_ptrank;
     WS_ALLOC(d_stage, sizeof(float) * 5 * static_cast<size_t>(F) * pt_cap);
     WS_ALLOC(d_packed, sizeof(PackedFrame) * F);
+    WS_ALLOC(d_lite, sizeof(PackedLite) * F);
+    WS_ALLOC(d_tailc, sizeof(vtd::TailCluster) * vtd::TP_MAXC * static_cast<size_t>(F));
+    WS_ALLOC(d_dets, sizeof(vtd::FrameDets) * F);
+    WS_ALLOC(d_job_be, sizeof(uint32_t) * 2 * F);
     WS_ALLOC(d_members_big, sizeof(CandMemberX) * static_cast<size_t>(std::max<uint32_t>(vox_cap, 1)));
     WS_ALLOC(fs.rowT, sizeof(unsigned long long) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.rowQ, sizeof(uint32_t) * 4 * FR_ROWS_MAX * static_cast<size_t>(F));
@@ -274,8 +356,16 @@ struct Workspace
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_lite), sizeof(PackedLite) * F)) != hipSuccess)
+      return e;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_dets), sizeof(vtd::FrameDets) * F)) != hipSuccess)
+      return e;
     h_args.assign(F, FrameArgs{});
     if ((e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess)
+      return e;
+    if ((e = hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)) != hipSuccess)
+      return e;
+    if ((e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)) != hipSuccess)
       return e;
     // the memsets above run on the null stream, the kernels on non-blocking streams: wait for the fills to land
     return hipDeviceSynchronize();
@@ -332,6 +422,7 @@ struct vofod_handle
   unsigned long long* d_counter = nullptr;  // scratch words
   unsigned long long *d_bgcount = nullptr, *h_bgcount = nullptr;  // MB_SLOTS partial nVoxelsOver counters (64 B apart); host pinned copy
   bool bgcount_fresh = false;
+  hipEvent_t ev_explore = nullptr;  // the shared flood-fill buffers are free again (device tails of batches on different streams take turns)
   hipEvent_t ev_bgcount = nullptr;  // recorded behind the device-to-host copy of the background count: waited for before the count is consumed
   unsigned long long* h_counter = nullptr;  // pinned
   bool mapbits_valid = false;
@@ -1562,14 +1653,102 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, keep_dirty ? nullptr : ws.d_bitmaps);
   ws.bitmap_clean = frame_path ? bitmap_was_clean : !keep_dirty;
   ws.finalize_fused = false;
-  KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
-  HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
+  static const bool lite_on = !(std::getenv("VOFOD_LITE") && std::atoi(std::getenv("VOFOD_LITE")) == 0);
+  static const bool dtail_on = !(std::getenv("VOFOD_DEVICE_TAIL") && std::atoi(std::getenv("VOFOD_DEVICE_TAIL")) == 0);
+  ws.dtail = dtail_on && !dbg && n >= 4 && no_update;
+  ws.lite = !ws.dtail && lite_on && !dbg && n >= 4 && no_update;
+  if (ws.dtail)
+  {
+    // Classification tail on the device (kernels_tail.h): boxes + gates, flood fills, detection records; nothing comes back
+    // but the records.  The background latch (:716-721) is needed now, not at collect time.
+    if (h->bgcount_fresh)
+    {
+      if (h->ev_bgcount)
+        HIPCHK(hipEventSynchronize(h->ev_bgcount));
+      uint64_t t = 0;
+      for (int i = 0; i < MB_SLOTS; i++)
+        t += h->h_bgcount[8 * i];
+      h->n_bg_voxels = t;
+      h->bgcount_fresh = false;
+    }
+    if (h->n_bg_voxels > h->background_min_sufficient_pts)
+      h->background_pts_sufficient = true;
+    r = ensure_explore(h, h->ws.F, static_cast<size_t>(h->ws.F) * vtd::TP_MAXC, static_cast<size_t>(h->ws.F) * vtd::TP_MAXM);
+    if (r != VOFOD_OK)
+      return r;
+    // A submitted batch runs its tail on the handle's tail stream: one wave per frame does the flood fills (latency bound,
+    // ~0.1 ms), which overlaps with the streaming kernels of the next batch instead of delaying them.  The tail stream also
+    // serialises the tails of the batches in flight on the shared flood-fill buffers.
+    hipStream_t chain_stream = h->stream;
+    struct TailStream
+    {
+      vofod_handle* h;
+      hipStream_t saved;
+      ~TailStream() { h->stream = saved; }
+    } tail_guard{h, h->stream};
+    if (!h->ev_explore)
+      HIPCHK(hipEventCreateWithFlags(&h->ev_explore, hipEventDisableTiming));
+    if (phase == FRAMES_LAUNCH && h->stream_tail)
+    {
+      HIPCHK(hipEventRecord(ws.ev_packed, chain_stream));  // the cluster tables of this batch are complete
+      h->stream = h->stream_tail;
+      HIPCHK(hipStreamWaitEvent(h->stream, ws.ev_packed, 0));
+    }
+    else
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_explore, 0));  // (a synchronous call: wait for the tails of batches in flight)
+    ExploreBufs& eb = h->explore;
+    vtd::TailParams tp{};
+    tp.min_points = dp.classification__min_points;
+    tp.max_distance = dp.classification__max_distance;
+    tp.max_size = dp.classification__max_size;
+    tp.max_explore = dp.classification__max_explore_distance;
+    tp.voxel_size = sp.voxel_size;
+    tp.latches = (h->background_pts_sufficient && h->sure_background_sufficient) ? 1 : 0;
+    vc::ExploreParams ep{};
+    ep.thr_unknown = static_cast<float>(dp.voxel_map__thresholds__frontiers);
+    ep.thr_ground = thr_new;
+    ep.frontier_value = static_cast<float>(dp.voxel_map__thresholds__frontiers);
+    ep.ray_score = dp.voxel_map__scores__ray;
+    ep.no_update = 1;
+    ep.stack_cap = vc::EX_CELLS;
+    KLAUNCH(h, vtd::k_tail_prep, dim3(n), dim3(vtd::TP_THREADS), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, ws.d_tailc,
+            ws.d_dets);
+    KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched, eb.d_ovl_list,
+            eb.d_ovl_count, eb.d_results);
+    KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets);
+    HIPCHK(hipEventRecord(h->ev_explore, h->stream));
+    if (phase == FRAMES_LAUNCH)
+    {
+      HIPCHK(hipEventRecord(ws.ev_packed, h->stream));
+      HIPCHK(hipStreamWaitEvent(ws.copy_stream, ws.ev_packed, 0));
+      HIPCHK(hipMemcpyAsync(ws.h_dets, ws.d_dets, sizeof(vtd::FrameDets) * n, hipMemcpyDeviceToHost, ws.copy_stream));
+    }
+    else
+      HIPCHK(hipMemcpyAsync(ws.h_dets, ws.d_dets, sizeof(vtd::FrameDets) * n, hipMemcpyDeviceToHost, h->stream));
+  }
+  else if (ws.lite)
+  {
+    KLAUNCH(h, k_pack_lite, dim3(n), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_lite);
+    if (phase == FRAMES_LAUNCH)
+    {
+      HIPCHK(hipEventRecord(ws.ev_packed, h->stream));
+      HIPCHK(hipStreamWaitEvent(ws.copy_stream, ws.ev_packed, 0));
+      HIPCHK(hipMemcpyAsync(ws.h_lite, ws.d_lite, sizeof(PackedLite) * n, hipMemcpyDeviceToHost, ws.copy_stream));
+    }
+    else
+      HIPCHK(hipMemcpyAsync(ws.h_lite, ws.d_lite, sizeof(PackedLite) * n, hipMemcpyDeviceToHost, h->stream));
+  }
+  else
+  {
+    KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
+    HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
+  }
   if (dbg)
     HIPCHK(hipEventRecord(ev[4], h->stream));
   tr_launch = ms_since(t0);
   if (phase == FRAMES_LAUNCH)
   {
-    HIPCHK(hipEventRecord(ws.ev_done, h->stream));
+    HIPCHK(hipEventRecord(ws.ev_done, (ws.lite || ws.dtail) ? ws.copy_stream : h->stream));
     ws.pending = true;
     ws.job_n = n;
     ws.job_g = g;
@@ -1590,6 +1769,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   else
     HIPCHK(hipStreamSynchronize(h->stream));
   tr_sync1 = ms_since(t0);
+  if (ws.lite)
+    for (uint32_t f = 0; f < n; f++)
+      ws.h_packed[f].hdr = ws.h_lite[f].hdr;  // the tail below reads the frames through the packed slots
+  if (ws.dtail)
+    for (uint32_t f = 0; f < n; f++)
+      ws.h_packed[f].hdr.status = ws.h_dets[f].status;
   for (uint32_t f = 0; f < n; f++)
     if (ws.h_packed[f].hdr.status == CCL_RETRY_STATUS)
     {
@@ -1637,6 +1822,61 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     }
   }
 
+  if (ws.dtail)
+  {
+    // ---- the tail ran on the device: extractDetections' record (:848-877) from the raw detections, frame by frame
+    uint32_t fb = 0;
+    for (uint32_t f = 0; f < n; f++)
+      fb |= ws.h_dets[f].fallback;
+    if (!fb)
+    {
+      size_t total = 0;
+      for (uint32_t f = 0; f < n; f++)
+      {
+        const vtd::FrameDets& D = ws.h_dets[f];
+        if (D.status != VOFOD_OK)
+          ret = D.status;
+        const float* tf = tfs + 12 * f;
+        const float tpos[3] = {tf[3], tf[7], tf[11]};
+        for (uint32_t i = 0; i < D.n; i++)
+        {
+          const vtd::DetRaw& R = D.d[i];
+          vofod_detection det{};
+          const float d[3] = {tpos[0] - R.center[0], tpos[1] - R.center[1], tpos[2] - R.center[2]};
+          const double det_dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          det.id = h->last_detection_id++;
+          det.frame = f;
+          det.n_points = R.n_points;
+          const float cov = static_cast<float>(std::sqrt(det_dist) * dp.output__position_sigma);
+          for (int q = 0; q < 3; q++)
+            det.covariance[4 * q] = cov;
+          const double u = R.conf_sum / R.n_points;  // :860-865
+          det.confidence = static_cast<float>(1.0 / std::exp(u));
+          const double vray_res = sp.sensor_vfov / static_cast<double>(sp.sensor_vrays);
+          const double hray_res = 2 * M_PI / static_cast<double>(sp.sensor_hrays);
+          det.detection_probability = std::min(std::atan(1.0 / det_dist) / (vray_res * dp.classification__min_points), 1.0) * std::min(std::atan(1.0 / det_dist) / hray_res, 1.0);
+          for (int a = 0; a < 3; a++)
+            det.position[a] = R.center[a];
+          if (out && total < cap)
+            out[total] = det;
+          total++;
+        }
+        if (n_out_per_frame)
+          n_out_per_frame[f] = D.n;
+      }
+      if (trace)
+        std::fprintf(stderr, "[vofod trace] n=%u device tail: sync %.3f end %.3f ms, %zu detections\n", n, tr_sync1, ms_since(t0), total);
+      *n_out = total;
+      if (total > cap)
+        ret = VOFOD_ERR_CAPACITY;
+      return ret;
+    }
+    // a frame exceeded a capacity of the device tail: the host tail redoes the batch from the full tables
+    ws.dtail = false;
+    KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
+    HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   // ---- tail: classifyClusters :961 + extractDetections :963.
   // Host: canonical cluster order, OBB + gates of the few candidate clusters.  Device (k_explore): the flood
   // fills and uncertainty sums, one wave per frame, jobs of a frame in the reference's order.
@@ -1657,17 +1897,49 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // phase A (serial): frames whose tables overflowed the speculative read-back fetch the rest
   std::vector<std::vector<ClusterRec>> recs_big(n);
   std::vector<std::vector<CandMemberX>> members_big(n);
+  std::vector<uint8_t> big_recs(n, 0), big_members(n, 0);
   for (uint32_t f = 0; f < n; f++)
   {
-    const FrameHdr& hdr = ws.h_packed[f].hdr;
+    FrameHdr& hdr = ws.h_packed[f].hdr;
     if (hdr.status != VOFOD_OK)
       ret = hdr.status;
-    if (hdr.C > SPEC_C)
+    if (ws.lite)
     {
-      recs_big[f].resize(hdr.C);
-      HIPCHK(hipMemcpy(recs_big[f].data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
+      // lite read-back: only the candidate clusters' records came back; the header's C becomes their number
+      const PackedLite& L = ws.h_lite[f];
+      PackedFrame& pf = ws.h_packed[f];
+      if (L.n_recs <= LITE_C)
+      {
+        std::memcpy(pf.table, L.recs, sizeof(ClusterRec) * L.n_recs);
+        static_assert(LITE_C <= SPEC_C && LITE_M <= SPEC_M, "the lite lists are unpacked into the packed slot");
+      }
+      else
+      {
+        // more candidate clusters than the lite slot holds: fetch the frame's whole table, keep the candidates
+        std::vector<ClusterRec> all(hdr.C);
+        HIPCHK(hipMemcpy(all.data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
+        for (const ClusterRec& r : all)
+          if (r.cand && !r.close)
+            recs_big[f].push_back(r);
+        big_recs[f] = 1;
+      }
+      hdr.C = L.n_recs;
+      if (L.n_members <= LITE_M)
+        std::memcpy(pf.members, L.members, sizeof(CandMemberX) * L.n_members);
+      else
+        big_members[f] = 1;
     }
-    if (hdr.n_cand > SPEC_M)
+    else
+    {
+      big_recs[f] = hdr.C > SPEC_C;
+      big_members[f] = hdr.n_cand > SPEC_M;
+      if (big_recs[f])
+      {
+        recs_big[f].resize(hdr.C);
+        HIPCHK(hipMemcpy(recs_big[f].data(), ws.d_table + static_cast<size_t>(f) * ws.vox_cap, sizeof(ClusterRec) * hdr.C, hipMemcpyDeviceToHost));
+      }
+    }
+    if (big_members[f])
     {
       members_big[f].resize(hdr.n_cand);
       CandMemberX* d_tmp = static_cast<CandMemberX*>(ws.d_members_big);  // n_cand <= V <= vox_cap: sized with the workspace
@@ -1683,8 +1955,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     FrameTail& T = tails[f];
     const PackedFrame& pf = ws.h_packed[f];
     const FrameHdr& hdr = pf.hdr;
-    const ClusterRec* recs = hdr.C > SPEC_C ? recs_big[f].data() : pf.table;
-    const CandMemberX* members = hdr.n_cand > SPEC_M ? members_big[f].data() : pf.members;
+    const ClusterRec* recs = big_recs[f] ? recs_big[f].data() : pf.table;
+    const CandMemberX* members = big_members[f] ? members_big[f].data() : pf.members;
     // canonical order: size desc, smallest member asc
     T.cl.resize(hdr.C);
     for (uint32_t c = 0; c < hdr.C; c++)
@@ -1809,6 +2081,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       ~StreamSwap() { h->stream = saved; }
     } swap_guard(h, phase == FRAMES_COLLECT);
     ExploreBufs& eb = h->explore;
+    if (h->ev_explore)
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_explore, 0));  // a device tail in flight may still use the flood-fill buffers
     HIPCHK(hipMemcpyAsync(eb.d_jobs, jobs.data(), sizeof(vc::ExploreJob) * jobs.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(eb.d_job_begin, job_begin.data(), sizeof(uint32_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(eb.d_members, job_members.data(), sizeof(int) * job_members.size(), hipMemcpyHostToDevice, h->stream));
@@ -1819,9 +2093,11 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ep.ray_score = dp.voxel_map__scores__ray;
     ep.no_update = no_update;
     ep.stack_cap = vc::EX_CELLS;
-    KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, eb.d_job_begin, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
+    KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, eb.d_job_begin, eb.d_job_begin + 1, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
             eb.d_ovl_list, eb.d_ovl_count, eb.d_results);
     HIPCHK(hipMemcpyAsync(results.data(), eb.d_results, sizeof(vc::ExploreResult) * jobs.size(), hipMemcpyDeviceToHost, h->stream));
+    if (h->ev_explore)
+      HIPCHK(hipEventRecord(h->ev_explore, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (!no_update)
       h->mapbits_valid = false;
