@@ -938,37 +938,45 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     return raw << shw;
   };
   {
+    // the adjacent bricks sit in at most five stencil rows ((dy, dz) in the half stencil with |dy|, |dz| <= 1): lane `sub`
+    // of the eight lanes of a brick serves the sub-th of them for every brick, its descriptor stays in registers
     const int sub = tid % LB_LANES;
-    // a lane serves the same two stencil rows for every brick: their descriptors stay in registers
-    int ddyv[RPL], ddzv[RPL];
-    uint32_t validv[RPL], axisv[RPL], nearv[RPL];
-    unsigned long long ovv[RPL];
-#pragma unroll
-    for (int rr = 0; rr < RPL; rr++)
+    int ddy = 0, ddz = 0;
+    uint32_t valid = 0, axis = 0;
+    unsigned long long ov = 0;
     {
-      load_row(rr * LB_LANES + sub, ddyv[rr], ddzv[rr], validv[rr], axisv[rr], nearv[rr], ovv[rr]);
-      validv[rr] &= nearv[rr];  // D-a1: adjacent bricks only
+      int k = 0;
+      for (int row = 0; row < n_rows; row++)
+      {
+        int y, z;
+        uint32_t v, ax, nr;
+        unsigned long long o;
+        load_row(row, y, z, v, ax, nr, o);
+        if (!(v & nr))
+          continue;
+        if (k == sub)
+        {
+          ddy = y;
+          ddz = z;
+          valid = v & nr;
+          axis = ax;
+          ov = o;
+        }
+        k++;
+      }
     }
     const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
     for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservations below scan the wave
     {
       const bool live = t < n;
       const uint32_t xyz = live ? s_xyz[t] : 0u;
-      const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
-      uint32_t winv[RPL], rawv[RPL], nbv[RPL];
-      int shv[RPL];
-#pragma unroll
-      for (int rr = 0; rr < RPL; rr++)
-      {
-        winv[rr] = rawv[rr] = nbv[rr] = 0;
-        shv[rr] = 0;
-        const int ny = by + ddyv[rr], nz = bz + ddzv[rr];
-        if (live && validv[rr] && ny >= 0 && ny < nby && nz < nbz)
-          winv[rr] = window(bx, ny, nz, rawv[rr], nbv[rr], shv[rr]) & validv[rr];
-      }
+      const int bx = fr_bx(xyz), ny = fr_by(xyz) + ddy, nz = fr_bz(xyz) + ddz;
+      uint32_t win = 0, raw = 0, nb0 = 0;
+      int shw = 0;
+      if (live && valid && ny >= 0 && ny < nby && nz < nbz)
+        win = window(bx, ny, nz, raw, nb0, shw) & valid;
       // one reservation per wave and list
-      const uint32_t kA = __popc(winv[0] & axisv[0]) + __popc(winv[1] & axisv[1]);
-      const uint32_t kN = __popc(winv[0] & ~axisv[0]) + __popc(winv[1] & ~axisv[1]);
+      const uint32_t kA = __popc(win & axis), kN = __popc(win & ~axis);
       const uint32_t iA = wave_incl_scan(kA), iN = wave_incl_scan(kN);
       uint32_t bA = 0, bN = 0;
       if (lane == 63)
@@ -979,22 +987,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           bN = atomicAdd(&s_nn, iN);
       }
       uint32_t pA = __builtin_amdgcn_readlane(bA, 63) + iA - kA, pN = __builtin_amdgcn_readlane(bN, 63) + iN - kN;
-#pragma unroll
-      for (int rr = 0; rr < RPL; rr++)
+      while (win)
       {
-        uint32_t win = winv[rr];
-        while (win)
-        {
-          const int sl = __ffs(static_cast<int>(win)) - 1;
-          win &= win - 1;
-          const uint32_t o = static_cast<uint32_t>(ovv[rr] >> (8 * sl)) & 0xffu;
-          const uint32_t t2 = nbv[rr] + __popc(rawv[rr] & ((1u << (sl - shv[rr])) - 1u));
-          const uint32_t hv = t | (t2 << 13) | (o << 26);
-          if ((axisv[rr] >> sl) & 1u)
-            hits[pA++] = hv;
-          else
-            hits_near[pN++] = hv;
-        }
+        const int sl = __ffs(static_cast<int>(win)) - 1;
+        win &= win - 1;
+        const uint32_t o = static_cast<uint32_t>(ov >> (8 * sl)) & 0xffu;
+        const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+        const uint32_t hv = t | (t2 << 13) | (o << 26);
+        if ((axis >> sl) & 1u)
+          hits[pA++] = hv;
+        else
+          hits_near[pN++] = hv;
       }
     }
   }
@@ -1155,48 +1158,49 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __syncthreads();
   const uint32_t n_small = s_nn;
   {
-    // work item = (brick outside G, stencil row, direction); the row descriptors of an item come from LDS each time
+    // work item = (brick outside G, stencil row, direction).  A thread's items all have the same (row, direction) when the
+    // stride is a multiple of 32: the row's descriptor and its far slots are decoded once.
     const uint32_t items = n_small * 32u;
-    for (uint32_t it = tid; it < items; it += FR_THREADS)
+    const int row = (tid >> 1) & 15, back = tid & 1;
+    int ddy, ddz;
+    uint32_t valid, axis, near;
+    unsigned long long ov;
+    load_row(row, ddy, ddz, valid, axis, near, ov);
+    uint32_t far = valid & ~near;  // slots of the half stencil two bricks away (forward view)
+    if (back)
     {
-      const uint32_t t = small[it >> 5];
-      const int row = (it >> 1) & 15, back = it & 1u;
-      int ddy, ddz;
-      uint32_t valid, axis, near;
-      unsigned long long ov;
-      load_row(row, ddy, ddz, valid, axis, near, ov);
-      uint32_t far = valid & ~near;  // slots of the half stencil two bricks away (forward view)
-      if (!far)
-        continue;
-      if (back)
-      {
-        // the neighbour is the pair's base brick: it sees this brick at (-dx, ddy, ddz), i.e. slot 2R - s
-        uint32_t rev = 0;
-        for (int sl = 0; sl <= 2 * R; sl++)
-          rev |= ((far >> (2 * R - sl)) & 1u) << sl;
-        far = rev;
-      }
-      const uint32_t xyz = s_xyz[t];
-      const int bx = fr_bx(xyz), ny = fr_by(xyz) + (back ? -ddy : ddy), nz = fr_bz(xyz) + (back ? -ddz : ddz);
-      if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
-        continue;
-      uint32_t raw, nb0;
-      int shw;
-      uint32_t win = window(bx, ny, nz, raw, nb0, shw) & far;
-      const uint32_t rt = lb_ld16(s_par, t);
-      while (win)
-      {
-        const int sl = __ffs(static_cast<int>(win)) - 1;
-        win &= win - 1;
-        const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
-        if (lb_ld16(s_par, t2) == rt)
-          continue;  // one component already
-        const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
-        const uint32_t pos = atomicAdd(&s_nf, 1u);
-        if (pos < cap_far)
-          hits_far[pos] = back ? (t2 | (t << 13) | (o << 26)) : (t | (t2 << 13) | (o << 26));
-      }
+      // the neighbour is the pair's base brick: it sees this brick at (-dx, ddy, ddz), i.e. slot 2R - s
+      uint32_t rev = 0;
+      for (int sl = 0; sl <= 2 * R; sl++)
+        rev |= ((far >> (2 * R - sl)) & 1u) << sl;
+      far = rev;
     }
+    static_assert(FR_THREADS % 32 == 0, "items of a thread share row and direction");
+    if (far)
+      for (uint32_t it = tid; it < items; it += FR_THREADS)
+      {
+        const uint32_t t = small[it >> 5];
+        const uint32_t xyz = s_xyz[t];
+        const int bx = fr_bx(xyz), ny = fr_by(xyz) + (back ? -ddy : ddy), nz = fr_bz(xyz) + (back ? -ddz : ddz);
+        if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
+          continue;
+        uint32_t raw, nb0;
+        int shw;
+        uint32_t win = window(bx, ny, nz, raw, nb0, shw) & far;
+        const uint32_t rt = lb_ld16(s_par, t);
+        while (win)
+        {
+          const int sl = __ffs(static_cast<int>(win)) - 1;
+          win &= win - 1;
+          const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+          if (lb_ld16(s_par, t2) == rt)
+            continue;  // one component already
+          const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
+          const uint32_t pos = atomicAdd(&s_nf, 1u);
+          if (pos < cap_far)
+            hits_far[pos] = back ? (t2 | (t << 13) | (o << 26)) : (t | (t2 << 13) | (o << 26));
+        }
+      }
   }
   __syncthreads();
   const uint32_t nh_far = s_nf;
@@ -1270,6 +1274,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     prof[static_cast<size_t>(FRAME) * 32 + 28] = s_ne;
     prof[static_cast<size_t>(FRAME) * 32 + 29] = V;
     prof[static_cast<size_t>(FRAME) * 32 + 30] = n_surv;
+    prof[static_cast<size_t>(FRAME) * 32 + 31] = n_small | (static_cast<unsigned long long>(nh_far) << 32);
   }
   // ---- E: component minima: the smallest voxel rank of a component is the first voxel of one of its bricks
   uint32_t my_root[LB_MAX / FR_THREADS], my_min[LB_MAX / FR_THREADS];

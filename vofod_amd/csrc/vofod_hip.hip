@@ -1199,7 +1199,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
                          t[32 * f + 26], t[32 * f + 28], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30]);
             for (int i = 0; i < 13; i++)
               std::fprintf(stderr, " %s %.1f", names[i], (t[32 * f + i + 1] - t[32 * f + i]) * 0.01);
-            std::fprintf(stderr, " (count %.1f of rank-a/b)\n", (t[32 * f + 14] - t[32 * f + 3]) * 0.01);
+            std::fprintf(stderr, " (count %.1f of rank-a/b; %llu bricks outside the largest component, %llu far hits)\n", (t[32 * f + 14] - t[32 * f + 3]) * 0.01, t[32 * f + 31] & 0xffffffffull,
+                         t[32 * f + 31] >> 32);
           }
           if (!byd.empty())
             std::fprintf(stderr, "[k_frame_lds] %zu workgroups: span %.1f us, mean %.1f us\n", byd.size(), (t1 - t0) * 0.01, mean);
