@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — LiDAR frames/s of the per-scan hot path on MI355X (BASELINE.json metric).
 
-A step = one `vofod_process_batch` call over F independent synthetic OS1-128 scans (131 072 points each,
-0.25 m voxels: BASELINE.json configs[1] in the batched form of configs[3]) against a pre-warmed voxel map,
-inputs already resident in HBM.  With N GPUs every rank processes its own F frames per step (weak scaling,
-no data-path collective) and the fixed-size detection records are all-gathered with RCCL at the end of
-each step.  Prints ONE JSON line on rank 0.
+A step = one batch of F independent synthetic OS1-128 scans (131 072 points each, 0.25 m voxels:
+BASELINE.json configs[1] in the batched form of configs[3]) through vofod_batch_submit/collect against a
+pre-warmed voxel map, inputs already resident in HBM.  With N GPUs every rank processes its own F frames per
+step (weak scaling, no data-path collective; `--scaling strong` splits F frames over the ranks instead) and
+the fixed-size detection records are all-gathered with RCCL at the end of each step.  Prints ONE JSON line
+on rank 0.
 """
 from __future__ import annotations
 
@@ -39,6 +40,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (1..4); their kernel chains overlap on the device")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --frames per GPU per step; strong: --frames in total per step, split over the GPUs (configs[3]: 256 scans over 8 GPUs)")
     return ap.parse_args()
 
 
@@ -82,7 +84,7 @@ def main():
     from vofod_amd.detector import ScanData
 
     lib = vofod_amd.library()
-    F = args.frames
+    F = args.frames if args.scaling == "weak" else max(4, args.frames // world)
     det = build_detector(lib, args.sensor, args.voxel_size, F, local_rank)
     scene = synth.bench_scene()
     synth.warm_map(det, scene, args.sensor, args.map_warm_scans)
@@ -168,7 +170,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -199,6 +201,27 @@ def main():
         single_ms = 1e3 * (time.perf_counter() - t1) / (len(seq) - 1)
         out["single_stream"] = {"ms_per_scan": single_ms, "frames_per_s": 1e3 / single_ms, "note": "sequential vofod_process_scan with map update, device-resident input"}
 
+        if F > 32:
+            # configs[3] spreads 256 scans over 8 GPUs: 32 per GPU and step.  The same handle, batches of 32 frames.
+            sub, sub_tfs = scans[:32], tfs[:32]
+
+            def run32(k):
+                infl = []
+                for _ in range(k):
+                    infl.append(det.batch_submit(sub, sub_tfs))
+                    if len(infl) == args.inflight:
+                        det.batch_collect(infl.pop(0))
+                while infl:
+                    det.batch_collect(infl.pop(0))
+
+            run32(5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run32(100)
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t1
+            out["config3_share"] = {"frames_per_gpu_per_step": 32, "frames_per_s": 32 * 100 / dt32, "ms_per_step": 1e3 * dt32 / 100,
+                                    "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU; one workgroup per frame leaves 7/8 of the CUs idle in k_frame_lds"}
         if not args.no_profile_pass:
             out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F)
         if args.cpu_baseline_scans > 0:
@@ -230,12 +253,17 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
     # algorithmic bytes per launch: every launch covers F frames
     M = det.n_voxels
     alg = {
-        "k_bbox": 12.0 * n_pts * F,
+        # batched fast path (kernels_frame.h)
+        "k_bbox": 12.0 * n_pts * F,          # bounding box: one read of the xyz columns
+        "k_key2<true>": 12.0 * n_pts * F,    # brick codes: the second read of the same columns (counted again here, once in the path total)
+        "k_key2<false>": 12.0 * n_pts * F,
+        "k_frame_lds": 40.0 * V * F,         # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
+        # general path (single scans, fallbacks)
         "k_setbits": 12.0 * n_pts * F,
         "k_key": 12.0 * n_pts * F,
-        "k_slab": 4.0 * V * F,             # the surviving points' keys (at least one per voxel)
-        "k_slab_emit": 28.0 * V * F,       # keys in (>= 4*V), voxel records out (pts 16 + key 4 + brick code 4)
-        "k_brick_ccl_lds": 16.0 * V * F,   # the whole neighbourhood + link stage of the clustering, inside LDS
+        "k_slab": 4.0 * V * F,
+        "k_slab_emit": 28.0 * V * F,
+        "k_brick_ccl_lds": 16.0 * V * F,
         "k_flatten<2>": 8.0 * V * F,
         "k_count": 12.0 * n_pts * F,
         "k_emit": 20.0 * V * F,
@@ -243,10 +271,9 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_flatten<0>": 8.0 * V * F,
         "k_flatten<1>": 8.0 * V * F,
         "k_brick_set": 4.0 * V * F,
-        # clustering stage of SURVEY 8d = read centres/keys 16*V + write labels 4*V + member list 4*V, split over its kernels:
-        "k_brick_union<1>": 20.0 * V * F,  # fused probe + link
-        "k_brick_conn": 16.0 * V * F,      # neighbourhood pass over the voxel positions (held as brick bits)
-        "k_brick_link_tr": 4.0 * V * F,    # component links = the labels' worth
+        "k_brick_union<1>": 20.0 * V * F,
+        "k_brick_conn": 16.0 * V * F,
+        "k_brick_link_tr": 4.0 * V * F,
         "k_brick_link": 4.0 * V * F,
         "k_brick_root": 4.0 * V * F,
         "k_closefar": 4.0 * V * F,
@@ -258,17 +285,24 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
             k["alg_bytes"] = alg[nm]
             k["GBps"] = alg[nm] / (k["avg_us"] * 1e-6) / 1e9
     # the voxelize+cluster path of north_star: K1-K7 (either clustering family)
-    path_prefixes = ("k_init_hdr", "k_bbox", "k_grid", "k_setbits", "k_key", "k_slab", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten", "k_brick_")
+    path_prefixes = ("k_init_hdr", "k_bbox", "k_grid", "k_setbits", "k_key", "k_frame_lds", "k_slab", "k_scan_a", "k_scan_b", "k_emit", "k_count", "k_union", "k_flatten", "k_brick_")
     path = [k for k in kernels if k.startswith(path_prefixes)]
     path_us = sum(kernels[p]["avg_us"] for p in path)
     dom = max(path, key=lambda p: kernels[p]["avg_us"])
     dk = kernels[dom]
-    traffic = None
-    tr_file = ROOT / "profiles" / "r01_traffic.json"
-    if tr_file.exists():  # PMC passes of this same command (tools/run_profiles.sh), corrected per MI355X_MICROARCH.md
+    # HBM traffic of the dominant kernel from the PMC passes of this same command (tools/run_profiles.sh ->
+    # profiles/r02_traffic.json, corrected per MI355X_MICROARCH.md).  The file records the hash of the kernel sources it was
+    # measured on: a number from other sources would be stale and is not reported.
+    traffic, traffic_note = None, "no PMC summary for these kernel sources (run tools/run_profiles.sh)"
+    tr_file = ROOT / "profiles" / "r02_traffic.json"
+    if tr_file.exists():
         tr = json.loads(tr_file.read_text())
-        if dom in tr:
-            traffic = tr[dom]["hbm_bytes_per_launch_corrected"]
+        if tr.get("kernel_source_sha") == kernel_source_sha():
+            if dom in tr:
+                traffic = tr[dom]["hbm_bytes_per_launch_corrected"]
+                traffic_note = "profiles/r02_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, same command)"
+        else:
+            traffic_note = "profiles/r02_traffic.json was measured on other kernel sources: stale, not reported"
     roofline = {
         "bound": "hbm",
         "kernel": dom,
@@ -277,6 +311,7 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "unit": "GB/s",
         "frac": dk.get("GBps", 0.0) / HBM_PEAK_GBS,
         "traffic": traffic,
+        "traffic_source": traffic_note,
         "alg_bytes_per_launch": dk.get("alg_bytes"),
         "avg_launch_us": dk["avg_us"],
         "path": {
@@ -288,6 +323,16 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         },
     }
     return roofline, kernels
+
+
+def kernel_source_sha():
+    """hash of the kernel sources: ties a PMC traffic summary to the code it was measured on"""
+    import hashlib
+
+    hsh = hashlib.sha1()
+    for f in sorted((ROOT / "vofod_amd" / "csrc").glob("*.h")) + sorted((ROOT / "vofod_amd" / "csrc").glob("*.hip")):
+        hsh.update(f.read_bytes())
+    return hsh.hexdigest()
 
 
 def cpu_baseline(args, gpu_det, host_scans):

@@ -69,6 +69,10 @@ def main():
             "hbm_bytes_per_launch_raw": (t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / n,
             "hbm_bytes_per_launch_corrected": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / n,
         }
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha
+
+    out["kernel_source_sha"] = kernel_source_sha()  # bench.py reports `traffic` only for the sources it was measured on
     json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)
     print("wrote", f"profiles/{tag}_kernel_stats.csv", f"profiles/{tag}_traffic.json", len(out), "kernels")
 

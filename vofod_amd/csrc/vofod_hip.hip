@@ -249,7 +249,28 @@ struct Workspace
   vtd::FrameDets* d_dets = nullptr;
   vtd::FrameDets* h_dets = nullptr;  // pinned
   uint32_t* d_job_be = nullptr;      // [2][F]: first and one-past-last explore job of every frame
-  std::vector<FrameArgs> h_args;
+  // per-frame launch arguments in pinned host memory: their upload is a true asynchronous copy, so a batch is enqueued while the
+  // previous chain still runs (a copy from pageable memory makes the submitting thread wait for the stream)
+  struct PinnedArgs
+  {
+    FrameArgs* p = nullptr;
+    size_t n = 0;
+    FrameArgs& operator[](size_t i) { return p[i]; }
+    const FrameArgs& operator[](size_t i) const { return p[i]; }
+    FrameArgs* data() { return p; }
+    hipError_t assign(size_t n_, const FrameArgs& v)
+    {
+      if (p)
+        (void)hipHostFree(p);
+      p = nullptr;
+      n = n_;
+      if (hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(FrameArgs) * std::max<size_t>(n, 1)); e != hipSuccess)
+        return e;
+      for (size_t i = 0; i < n; i++)
+        p[i] = v;
+      return hipSuccess;
+    }
+  } h_args;
   bool bricks_preset = false;  // k_emit already registered the voxels in their bricks (fused brick_set)
   std::vector<vofod_scan> job_scans;  // the submitted batch (re-run when the LDS clustering kernel overflows)
   bool slab_bitmap = false;     // the current bitmaps were written by k_slab (dense, zeros included)
@@ -278,6 +299,8 @@ struct Workspace
       (void)hipHostFree(h_packed);
     if (h_lite)
       (void)hipHostFree(h_lite);
+    if (h_args.p)
+      (void)hipHostFree(h_args.p);
     if (h_dets)
       (void)hipHostFree(h_dets);
     if (ev_done)
@@ -360,7 +383,8 @@ struct Workspace
       return e;
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_dets), sizeof(vtd::FrameDets) * F)) != hipSuccess)
       return e;
-    h_args.assign(F, FrameArgs{});
+    if ((e = h_args.assign(F, FrameArgs{})) != hipSuccess)
+      return e;
     if ((e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess)
       return e;
     if ((e = hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)) != hipSuccess)

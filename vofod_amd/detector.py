@@ -80,6 +80,7 @@ class VoFOD:
                 setattr(self.sp, name, a.ctypes.data_as(C.c_void_p))
         self._scan_arrays = {}
         self._pending = {}
+        self._collect_bufs = {}
         self.h = C.c_void_p()
         st = lib.create(C.byref(self.sp), C.byref(self.dp), C.byref(self.h))
         if st != capi.OK:
@@ -229,11 +230,14 @@ class VoFOD:
 
     def batch_collect(self, ticket: int, det_cap: int = 4096):
         n = self._pending.pop(ticket)
-        dets = np.zeros(det_cap, dtype=capi.DETECTION)
-        per = np.zeros(n, dtype=np.uint32)
+        buf = self._collect_bufs.get((det_cap, n))  # reused between calls: the results are copied out below
+        if buf is None:
+            buf = (np.zeros(det_cap, dtype=capi.DETECTION), np.zeros(n, dtype=np.uint32))
+            self._collect_bufs[(det_cap, n)] = buf
+        dets, per = buf
         n_out = C.c_size_t(0)
         self._check(self.lib.batch_collect(self.h, ticket, capi.ptr(dets), det_cap, capi.ptr(per), C.byref(n_out)), "vofod_batch_collect")
-        return dets[: n_out.value].copy(), per
+        return dets[: n_out.value].copy(), per.copy()
 
     def raycast_begin(self, scan: ScanData, tf: np.ndarray, allow: Sequence[int] = ()):
         tfa = np.ascontiguousarray(tf, dtype=np.float32).reshape(12)
