@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/trace_${1:-x}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 5 --cpu-baseline-scans 0 --no-profile-pass > $OUT/log.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 5 --cpu-baseline-scans 0 --no-profile-pass ${BENCH_ARGS:-} > $OUT/log.txt 2>&1 || exit 1
 cd $R && python3 - <<PY
 import csv,glob
 rows=sorted(csv.DictReader(open(glob.glob('$OUT/**/*kernel_trace.csv',recursive=True)[0])),key=lambda r:int(r['Start_Timestamp']))
@@ -12,7 +12,7 @@ fr=[i for i,r in enumerate(rows) if 'k_frame_lds' in r['Kernel_Name'] and int(r[
 st=[int(rows[i]['Start_Timestamp']) for i in fr]
 d=[(b-a)/1e3 for a,b in zip(st,st[1:])]
 print('chain spacing us:', [round(x) for x in d[8:40]])
-i0=fr[20]-7; i1=fr[22]+6
+i0=fr[20]-9; i1=fr[23]+6
 t0=int(rows[i0]['Start_Timestamp']); prev=t0
 for r in rows[i0:i1]:
     s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])

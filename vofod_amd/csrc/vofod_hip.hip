@@ -446,6 +446,8 @@ struct vofod_handle
   unsigned long long* d_counter = nullptr;  // scratch words
   unsigned long long *d_bgcount = nullptr, *h_bgcount = nullptr;  // MB_SLOTS partial nVoxelsOver counters (64 B apart); host pinned copy
   bool bgcount_fresh = false;
+  hipEvent_t ev_stagger = nullptr;  // the streaming kernels of the batch submitted last have finished
+  bool ev_stagger_set = false;
   hipEvent_t ev_explore = nullptr;  // the shared flood-fill buffers are free again (device tails of batches on different streams take turns)
   hipEvent_t ev_bgcount = nullptr;  // recorded behind the device-to-host copy of the background count: waited for before the count is consumed
   unsigned long long* h_counter = nullptr;  // pinned
@@ -955,6 +957,10 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
       KLAUNCH(h, k_key2<true>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
     else
       KLAUNCH(h, k_key2<false>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
+    if (!h->ev_stagger)
+      HIPCHK(hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ev_stagger, h->stream));  // the next batch's chain may start its streaming kernels now
+    h->ev_stagger_set = true;
     ws.frame_fused = true;
     HIPCHK(hipGetLastError());
     return VOFOD_OK;
@@ -1554,8 +1560,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // In-flight batches on streams of their own overlap their kernel chains: a gain while a batch leaves CUs idle (32 / 64 /
   // 128 frames: +31 / +56 / +16 %), a loss once one batch's kernels fill the chip (256 frames: -6 %, co-running chains only
   // slow each other down).  VOFOD_TWO_CHAINS=0 / 1 forces one or the other.
+  // Round 2: the chains are staggered.  A batch's streaming kernels (bounding box, brick codes: HBM bound, a few waves per CU)
+  // start when the previous batch's have finished, i.e. while that batch's frame kernel (LDS bound, one workgroup per CU)
+  // runs: the two phases of consecutive batches share the chip instead of taking turns (VOFOD_STAGGER=0: free-running chains).
   static const int two_chains_env = std::getenv("VOFOD_TWO_CHAINS") ? std::atoi(std::getenv("VOFOD_TWO_CHAINS")) : -1;
-  const bool two_chains = two_chains_env >= 0 ? two_chains_env != 0 : n < 200;
+  static const bool stagger_on = !(std::getenv("VOFOD_STAGGER") && std::atoi(std::getenv("VOFOD_STAGGER")) == 0);
+  const bool two_chains = two_chains_env >= 0 ? two_chains_env != 0 : true;
   hipStream_t my_stream = nullptr;
   if (two_chains && phase == FRAMES_LAUNCH)
     for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
@@ -1564,6 +1574,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   if (phase != FRAMES_COLLECT)
   {
   ChainStream chain_guard(h, my_stream);
+  if (two_chains && stagger_on && phase == FRAMES_LAUNCH && h->ev_stagger_set)
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_stagger, 0));  // the previous batch's streaming kernels are through
   if (two_chains && phase == FRAMES_LAUNCH && !(h->mapbits_valid && h->mapbits_thr == thr_new))
   {
     // the occupancy image is shared by both chains: make sure it is complete before a second stream reads it
