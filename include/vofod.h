@@ -331,6 +331,14 @@ int vofod_ouster_lut(int32_t w, int32_t h, double range_unit, double lidar_origi
 int vofod_mask_layout(const uint8_t* image /* w*h, row-major */, int32_t w, int32_t h, const int32_t* pixel_shift_by_row /* h */,
                       int32_t mangle, uint8_t* mask /* w*h */);
 
+/* check_sensor_params (vofod_nodelet.cpp:1869-1917): the first valid pixel (mask set, range != 0; rows outer) of an organised
+ * host-resident cloud against the sensor model: direction of (point - beam offset) vs the LUT direction, its length vs
+ * range * 0.001 m, unit length of the LUT direction, each within 1e-3.  *checked (nullable) = a valid pixel was found
+ * (m_sensor_params_checked).  VOFOD_OK: the parameters fit or nothing could be checked; VOFOD_ERR_SIZE_MISMATCH: they do not
+ * (m_sensor_params_ok = false: the nodelet then refuses to raycast, :1413-1418).  lut_offsets and mask may be NULL. */
+int vofod_check_sensor_params(const vofod_scan* scan, const float* lut_directions /* 3*w*h */, const float* lut_offsets /* 3*w*h */, const uint8_t* mask /* w*h */,
+                              int32_t* checked);
+
 /* ------------------------------------------------------------ diagnostics */
 
 /* Per-kernel device time, measured with HIP events on the handle's own stream (the reference analogue is

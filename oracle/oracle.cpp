@@ -1195,6 +1195,46 @@ int ORACLE_API(mask_layout)(const uint8_t* image, int32_t w, int32_t hh, const i
   return VOFOD_OK;
 }
 
+// check_sensor_params (vofod_nodelet.cpp:1869-1917), statement by statement: rows outer, columns inner, the first pixel with
+// mask != 0 and range != 0 decides.  Eigen: (a - b).normalized() = v / sqrt(v.squaredNorm()), norm() = sqrt(x*x + y*y + z*z).
+int ORACLE_API(check_sensor_params)(const vofod_scan* scan, const float* lut_directions, const float* lut_offsets, const uint8_t* mask, int32_t* checked)
+{
+  if (!scan || !scan->x || !scan->y || !scan->z || !scan->range || !lut_directions || scan->memspace != VOFOD_MEM_HOST)
+    return VOFOD_ERR_INVALID_ARG;
+  bool found_valid = false, params_ok = true;
+  const float range_to_meters = 0.001f;
+  auto col_f = [&](const void* base, unsigned idx) { return *reinterpret_cast<const float*>(static_cast<const char*>(base) + static_cast<size_t>(idx) * scan->stride_bytes); };
+  auto col_u = [&](const void* base, unsigned idx) { return *reinterpret_cast<const uint32_t*>(static_cast<const char*>(base) + static_cast<size_t>(idx) * scan->stride_bytes); };
+  auto norm3 = [](const float v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  for (int row = 0; row < static_cast<int>(scan->height) && !found_valid; row++)
+    for (int col = 0; col < static_cast<int>(scan->width) && !found_valid; col++)
+    {
+      const unsigned idx = row * scan->width + col;
+      const uint32_t range = col_u(scan->range, idx);
+      if ((mask && !mask[idx]) || range == 0)  // :1882
+        continue;
+      const float* lut_dir = lut_directions + 3 * static_cast<size_t>(idx);
+      const float lut_dist = range_to_meters * float(range);
+      float v[3] = {col_f(scan->x, idx), col_f(scan->y, idx), col_f(scan->z, idx)};
+      if (lut_offsets)
+        for (int a = 0; a < 3; a++)
+          v[a] = v[a] - lut_offsets[3 * static_cast<size_t>(idx) + a];
+      const float pt_dist = norm3(v);                                                     // :1889
+      const float pt_dir[3] = {v[0] / pt_dist, v[1] / pt_dist, v[2] / pt_dist};           // :1888
+      const float diff[3] = {pt_dir[0] - lut_dir[0], pt_dir[1] - lut_dir[1], pt_dir[2] - lut_dir[2]};
+      if (norm3(diff) > 1e-3f)  // :1891
+        params_ok = false;
+      if (std::abs(pt_dist - lut_dist) > 1e-3f)  // :1896
+        params_ok = false;
+      if (1.0f - norm3(lut_dir) > 1e-3f)  // :1901
+        params_ok = false;
+      found_valid = true;
+    }
+  if (checked)
+    *checked = found_valid ? 1 : 0;
+  return params_ok ? VOFOD_OK : VOFOD_ERR_SIZE_MISMATCH;
+}
+
 int ORACLE_API(sim_lut)(int32_t w, int32_t h, float vfov, float* directions)
 {
   if (w < 2 || h < 2 || !directions)

@@ -400,3 +400,45 @@ def test_moie_boxes(oracle):
     # principal axis (1,-1)/sqrt2 spans [-1/sqrt2, 1/sqrt2]; the other (1,1)/sqrt2 spans proj {-.471,.236}
     np.testing.assert_allclose(ctr, [0.25, 0.25, 0.0], atol=1e-6)
     assert size[0] == pytest.approx(math.hypot(math.sqrt(2.0), math.sqrt(0.5)), rel=1e-5)
+
+
+def test_check_sensor_params(oracle):
+    """vofod_nodelet.cpp:1869-1917: the first pixel with mask != 0 and range != 0 is compared with the LUT (direction,
+    distance = range * 0.001, unit LUT vector), each within 1e-3; a scan without such a pixel leaves the check open"""
+    from vofod_amd.detector import check_sensor_params
+
+    w, h = 4, 2
+    lut = sim_lut(oracle, w, h, 0.5).reshape(h * w, 3)
+    rng_mm = np.uint32([0, 0, 12345, 2000, 3000, 4000, 5000, 6000])
+    xyz = (lut * (rng_mm[:, None].astype(np.float32) * np.float32(0.001))).astype(np.float32)
+
+    def scan_of(p, r):
+        return ScanData(x=np.ascontiguousarray(p[:, 0]), y=np.ascontiguousarray(p[:, 1]), z=np.ascontiguousarray(p[:, 2]), width=w, height=h,
+                        intensity=np.zeros(h * w, np.float32), range=np.ascontiguousarray(r), stride_bytes=4)
+
+    assert check_sensor_params(oracle, scan_of(xyz, rng_mm), lut) == (True, True)
+    # the first two pixels have no return: the third decides.  1.5 mm off in range: |pt_dist - lut_dist| > 1e-3 -> mismatch
+    bad = xyz.copy()
+    bad[2] = lut[2] * np.float32(12.3465)
+    assert check_sensor_params(oracle, scan_of(bad, rng_mm), lut) == (False, True)
+    # 0.5 mm off: within the tolerance
+    near = xyz.copy()
+    near[2] = lut[2] * np.float32(12.3455)
+    assert check_sensor_params(oracle, scan_of(near, rng_mm), lut) == (True, True)
+    # direction off by 2e-3 rad: |pt_dir - lut_dir| = 2e-3 > 1e-3
+    rot = xyz.copy()
+    c, s = np.cos(2e-3), np.sin(2e-3)
+    rot[2] = np.float32([c * xyz[2, 0] - s * xyz[2, 1], s * xyz[2, 0] + c * xyz[2, 1], xyz[2, 2]])
+    assert check_sensor_params(oracle, scan_of(rot, rng_mm), lut) == (False, True)
+    # masked out: pixel 2 is skipped, pixel 3 (consistent) decides although pixel 2 is wrong
+    mask = np.uint8([1, 1, 0, 1, 1, 1, 1, 1])
+    assert check_sensor_params(oracle, scan_of(bad, rng_mm), lut, mask=mask) == (True, True)
+    # a LUT vector that is not normalised: 1 - |lut_dir| > 1e-3
+    lut2 = lut.copy()
+    lut2[2] *= np.float32(0.99)
+    assert check_sensor_params(oracle, scan_of(xyz, rng_mm), lut2) == (False, True)
+    # beam offsets are subtracted before the comparison
+    offs = np.tile(np.float32([0.01, -0.02, 0.03]), (h * w, 1))
+    assert check_sensor_params(oracle, scan_of(xyz + offs, rng_mm), lut, lut_offsets=offs) == (True, True)
+    # no valid pixel at all: nothing checked, parameters not rejected
+    assert check_sensor_params(oracle, scan_of(xyz, np.zeros(h * w, np.uint32)), lut) == (True, False)

@@ -228,6 +228,7 @@ _SIGS = {
     "ingest_apriori": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_double, C.c_void_p, _P(C.c_size_t), _P(C.c_size_t)]),
     "ouster_lut": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mask_layout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "check_sensor_params": (C.c_int, [_P(Scan), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int32)]),
     "update_ground": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "read_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "write_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),

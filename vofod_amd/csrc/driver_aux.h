@@ -462,84 +462,161 @@ int vofod_sim_lut(int32_t w, int32_t hh, float vfov, float* directions)
 }
 
 
-// initialize_sensor_lut (vofod_nodelet.cpp:358-372).  [3P] ouster::make_xyz_lut restated from the published ouster_client
-// sources (ouster_example 2.x lidar_scan.cpp; the reference pins no version): per pixel i = u*w + v
-//   encoder = 2 pi - v * 2 pi / w,  azimuth = -az[u] deg,  altitude = alt[u] deg
-//   direction = (cos(enc + az) cos(alt), sin(enc + az) cos(alt), sin(alt))
-//   offset    = ((cos(enc), sin(enc), 0) - direction) * lidar_origin_to_beam_origin_mm
-//   both rotated by the lidar_to_sensor transform (offset also translated), both scaled by range_unit;
-// then the nodelet casts to float and normalises the directions column by column (:368-369).
+// initialize_sensor_lut (vofod_nodelet.cpp:358-372): the beam model of [3P] ouster::make_xyz_lut (ouster_client
+// lidar_scan.cpp; the reference pins no version) followed by the nodelet's float cast and per-column normalisation.
+// A beam of ring u at encoder column v leaves the lidar frame's z axis at radius n (= lidar_origin_to_beam_origin_mm) in the
+// encoder direction and points along (azimuth, altitude) of its ring:
+//   theta_enc = 2 pi - v 2 pi / w,   theta = theta_enc - azimuth[u],   phi = altitude[u]
+//   dir = (cos theta cos phi, sin theta cos phi, sin phi),   off = ((cos theta_enc, sin theta_enc, 0) - dir) n
+// both taken to the sensor frame by lidar_to_sensor (off also translated) and scaled by range_unit.
+// Product implementation: ring constants first, then a plain structure-of-rows sweep (the oracle restates the library loop).
+namespace
+{
+struct BeamRing
+{
+  double azimuth, cos_alt, sin_alt;
+};
+inline void to_sensor(const double rot[3][3], const double* trans, const double in[3], double out[3])
+{
+  // Eigen row-vector product with the transposed rotation block: ((x r0 + y r1) + z r2), then the translation
+  for (int j = 0; j < 3; j++)
+  {
+    out[j] = (in[0] * rot[j][0] + in[1] * rot[j][1]) + in[2] * rot[j][2];
+    if (trans)
+      out[j] += trans[j];
+  }
+}
+}  // namespace
+
 int vofod_ouster_lut(int32_t w, int32_t hh, double range_unit, double lidar_origin_to_beam_origin_mm, const double* tf16, const double* azimuth_deg, const double* altitude_deg,
                        float* directions, float* offsets)
 {
   if (w < 1 || hh < 1 || !azimuth_deg || !altitude_deg || !directions || !offsets)
     return VOFOD_ERR_INVALID_ARG;
-  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0};
+  double rot[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, trans[3] = {0, 0, 0};
   if (tf16)
     for (int r = 0; r < 3; r++)
     {
-      for (int c = 0; c < 3; c++)
-        R[3 * r + c] = tf16[4 * r + c];
-      T[r] = tf16[4 * r + 3];
+      std::copy(tf16 + 4 * r, tf16 + 4 * r + 3, rot[r]);
+      trans[r] = tf16[4 * r + 3];
     }
-  const double azimuth_radians = M_PI * 2.0 / w;
+  std::vector<BeamRing> rings(hh);
   for (int u = 0; u < hh; u++)
-    for (int v = 0; v < w; v++)
+  {
+    const double alt = altitude_deg[u] * M_PI / 180.0;
+    rings[u] = BeamRing{-azimuth_deg[u] * M_PI / 180.0, std::cos(alt), std::sin(alt)};
+  }
+  const double step = M_PI * 2.0 / w;
+  float* dir_out = directions;
+  float* off_out = offsets;
+  for (int u = 0; u < hh; u++)
+  {
+    const BeamRing& ring = rings[u];
+    for (int v = 0; v < w; v++, dir_out += 3, off_out += 3)
     {
-      const size_t i = static_cast<size_t>(u) * w + v;
-      const double encoder = 2.0 * M_PI - (v * azimuth_radians);
-      const double azimuth = -azimuth_deg[u] * M_PI / 180.0;
-      const double altitude = altitude_deg[u] * M_PI / 180.0;
-      double d[3] = {std::cos(encoder + azimuth) * std::cos(altitude), std::sin(encoder + azimuth) * std::cos(altitude), std::sin(altitude)};
-      double o[3] = {std::cos(encoder) - d[0], std::sin(encoder) - d[1], -d[2]};
-      for (int c = 0; c < 3; c++)
-        o[c] *= lidar_origin_to_beam_origin_mm;
-      // row vector times rot = transform.topLeftCorner(3,3).transpose(): element j = (d0*R[j][0] + d1*R[j][1]) + d2*R[j][2]
-      double dr[3], orr[3];
+      const double theta_enc = 2.0 * M_PI - (v * step), theta = theta_enc + ring.azimuth;
+      const double dir[3] = {std::cos(theta) * ring.cos_alt, std::sin(theta) * ring.cos_alt, ring.sin_alt};
+      const double off[3] = {(std::cos(theta_enc) - dir[0]) * lidar_origin_to_beam_origin_mm, (std::sin(theta_enc) - dir[1]) * lidar_origin_to_beam_origin_mm,
+                             (-dir[2]) * lidar_origin_to_beam_origin_mm};
+      double dir_s[3], off_s[3];
+      to_sensor(rot, nullptr, dir, dir_s);
+      to_sensor(rot, trans, off, off_s);
+      const float d32[3] = {static_cast<float>(dir_s[0] * range_unit), static_cast<float>(dir_s[1] * range_unit), static_cast<float>(dir_s[2] * range_unit)};
+      const float len = std::sqrt((d32[0] * d32[0] + d32[1] * d32[1]) + d32[2] * d32[2]);  // colwise().normalize() :369
       for (int j = 0; j < 3; j++)
       {
-        dr[j] = (d[0] * R[3 * j] + d[1] * R[3 * j + 1]) + d[2] * R[3 * j + 2];
-        orr[j] = ((o[0] * R[3 * j] + o[1] * R[3 * j + 1]) + o[2] * R[3 * j + 2]) + T[j];
+        dir_out[j] = d32[j] / len;
+        off_out[j] = static_cast<float>(off_s[j] * range_unit);
       }
-      float df[3];
-      for (int j = 0; j < 3; j++)
-      {
-        df[j] = static_cast<float>(dr[j] * range_unit);
-        offsets[3 * i + j] = static_cast<float>(orr[j] * range_unit);
-      }
-      const float norm = std::sqrt((df[0] * df[0] + df[1] * df[1]) + df[2] * df[2]);  // colwise().normalize() :369
-      for (int j = 0; j < 3; j++)
-        directions[3 * i + j] = df[j] / norm;
     }
+  }
   return VOFOD_OK;
 }
 
-// load_mask (vofod_nodelet.cpp:506-560) after cv::imread: the image (row-major, w x h, or NULL when the file is missing or
-// has the wrong size) is copied as is, or "mangled" (:527-541) into the staggered column-major order of the raw Ouster
-// packets, index ((v + pixel_shift_by_row[u]) % w) * h + u; entries no image provides are 1 (:558).
+// load_mask (vofod_nodelet.cpp:506-560) after cv::imread.  `image` is the decoded w x h picture (row-major) or NULL when the
+// file is missing or has the wrong size (then every ray is valid, :558).  With `mangle` (:527-541) the picture is rearranged
+// into the staggered column-major order of the raw Ouster packets: pixel (u, v) lands at ((v + pixel_shift_by_row[u]) % w) * h + u.
+// Product implementation: destination-major gather through the inverse shift (the oracle scatters source-major).
 int vofod_mask_layout(const uint8_t* image, int32_t w, int32_t hh, const int32_t* pixel_shift_by_row, int32_t mangle, uint8_t* mask)
 {
   if (w < 1 || hh < 1 || !mask)
     return VOFOD_ERR_INVALID_ARG;
-  const size_t n = static_cast<size_t>(w) * hh;
+  const size_t n_px = static_cast<size_t>(w) * hh;
   if (!image)
+    std::memset(mask, 1, n_px);
+  else if (!mangle)
+    std::memcpy(mask, image, n_px);
+  else
   {
-    std::fill(mask, mask + n, static_cast<uint8_t>(1));
-    return VOFOD_OK;
-  }
-  if (!mangle)
-  {
-    std::copy(image, image + n, mask);
-    return VOFOD_OK;
-  }
-  std::fill(mask, mask + n, static_cast<uint8_t>(0));  // std::vector::resize value-initialises (:519); every slot is written below
-  for (int u = 0; u < hh; u++)
-    for (int v = 0; v < w; v++)
+    // source column of destination column 0, per ring: v = (vv - shift) mod w.  A negative shift makes the reference index
+    // its vector out of range for the first columns (std::out_of_range): refused here.
+    std::vector<int32_t> back(hh);
+    for (int u = 0; u < hh; u++)
     {
-      const int shift = pixel_shift_by_row ? pixel_shift_by_row[u] : 0;
-      const size_t vv = static_cast<size_t>(v + shift) % static_cast<size_t>(w);
-      mask[vv * hh + u] = image[static_cast<size_t>(u) * w + v];
+      const int32_t sft = pixel_shift_by_row ? pixel_shift_by_row[u] : 0;
+      if (sft < 0)
+        return VOFOD_ERR_INVALID_ARG;
+      back[u] = (w - sft % w) % w;
     }
+    uint8_t* dst = mask;
+    for (int32_t vv = 0; vv < w; vv++)
+      for (int u = 0; u < hh; u++, dst++)
+      {
+        int32_t v = vv + back[u];
+        if (v >= w)
+          v -= w;
+        *dst = image[static_cast<size_t>(u) * w + v];
+      }
+  }
+  return VOFOD_OK;
+}
+
+// check_sensor_params (vofod_nodelet.cpp:1869-1917): the first valid pixel of an organised cloud (mask set, range != 0)
+// must agree with the sensor model: direction of (point - beam offset) equal to the LUT direction within 1e-3, its length
+// equal to range * 0.001 m within 1e-3, LUT direction of unit length within 1e-3.  *checked tells whether a valid pixel was
+// found (m_sensor_params_checked); the return value is VOFOD_OK when the parameters fit (or nothing could be checked) and
+// VOFOD_ERR_SIZE_MISMATCH - the reference's "parameters do not match the data" - otherwise.  Host arrays, w * h elements.
+int vofod_check_sensor_params(const vofod_scan* scan, const float* lut_directions, const float* lut_offsets, const uint8_t* mask, int32_t* checked)
+{
+  if (!scan || !scan->x || !scan->y || !scan->z || !scan->range || !lut_directions || scan->memspace != VOFOD_MEM_HOST)
+    return VOFOD_ERR_INVALID_ARG;
+  if (checked)
+    *checked = 0;
+  const size_t n_px = static_cast<size_t>(scan->width) * scan->height;
+  auto f32 = [&](const void* base, size_t i) {
+    float v;
+    std::memcpy(&v, static_cast<const char*>(base) + i * scan->stride_bytes, 4);
+    return v;
+  };
+  auto u32 = [&](const void* base, size_t i) {
+    uint32_t v;
+    std::memcpy(&v, static_cast<const char*>(base) + i * scan->stride_bytes, 4);
+    return v;
+  };
+  for (size_t idx = 0; idx < n_px; idx++)  // row-major: idx = row * width + col, rows outer as in the reference
+  {
+    const uint32_t range = u32(scan->range, idx);
+    if ((mask && !mask[idx]) || range == 0)
+      continue;
+    const float* ld = lut_directions + 3 * idx;
+    const float lut_dist = 0.001f * static_cast<float>(range);
+    float rel[3] = {f32(scan->x, idx), f32(scan->y, idx), f32(scan->z, idx)};
+    if (lut_offsets)
+      for (int a = 0; a < 3; a++)
+        rel[a] -= lut_offsets[3 * idx + a];
+    const float pt_dist = std::sqrt((rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2]);
+    float diff2 = 0.0f;
+    for (int a = 0; a < 3; a++)
+    {
+      const float d = rel[a] / pt_dist - ld[a];
+      diff2 += d * d;
+    }
+    const float lut_norm = std::sqrt((ld[0] * ld[0] + ld[1] * ld[1]) + ld[2] * ld[2]);
+    const bool ok = !(std::sqrt(diff2) > 1e-3f) && !(std::fabs(pt_dist - lut_dist) > 1e-3f) && !(1.0f - lut_norm > 1e-3f);
+    if (checked)
+      *checked = 1;
+    return ok ? VOFOD_OK : VOFOD_ERR_SIZE_MISMATCH;
+  }
   return VOFOD_OK;
 }
 

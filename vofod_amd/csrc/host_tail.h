@@ -310,68 +310,102 @@ inline bool explore_to_ground(const Geom& g, const Box& box, const float p[3], f
 }
 
 
-// initialize_apriori_map (vofod_nodelet.cpp:214-226, 306-345): rigid transform of the loaded cloud, stock
-// pcl::VoxelGrid<PointXYZ> centroid filter at the map's voxel size, centroids returned as xyz triples.
-// [3P] restated from PCL 1.10 voxel_grid.hpp / Eigen 3.3.7:
-//   tf = Identity; tf.rotate(AngleAxisf(yaw, UnitZ)); tf.translate(t + sim_correction)  ->  p' = R*p + R*(t+c)
-//   VoxelGrid: min_b = floor(min_p*inv), ijk = floor(x*inv) - min_b, idx = ijk . (1, dx, dx*dy), sort by idx,
-//   centroid = float sum of the run / count (order inside a run: input order; std::sort leaves it unspecified).
+// initialize_apriori_map (vofod_nodelet.cpp:214-226, 306-345): the loaded cloud goes through the rigid transform
+// tf = Identity . rotate(AngleAxisf(yaw, UnitZ)) . translate(t + sim_correction) and the stock pcl::VoxelGrid<PointXYZ>
+// centroid filter at the map's voxel size; the centroids come back as xyz triples in ascending cell order.
+// Product implementation (the oracle has its own, sort based): cells are found by a counting sort over the occupied cell
+// indices' hash buckets, which keeps the points of a cell in input order - the order the float sums are defined for
+// ([3P] PCL 1.10 voxel_grid.hpp sorts (idx, point) pairs; equal idx keep no specified order, input order is the stable one).
+struct AprioriGrid
+{
+  float inv;
+  int min_b[3], div_b[3];
+  bool ok;
+  uint32_t cell(const float* q) const
+  {
+    int ijk[3];
+    for (int r = 0; r < 3; r++)
+      ijk[r] = static_cast<int>(std::floor(q[r] * inv) - static_cast<float>(min_b[r]));
+    return static_cast<uint32_t>(ijk[0] + div_b[0] * (ijk[1] + div_b[1] * ijk[2]));
+  }
+};
+
 inline void ingest_apriori_points(const std::vector<float>& xyz_in, const float t[3], double yaw_deg, const float corr[3], float leaf, std::vector<float>& out)
 {
   out.clear();
-  const size_t n = xyz_in.size() / 3;
-  if (n == 0)
+  const size_t count = xyz_in.size() / 3;
+  if (!count)
     return;
+  // Eigen: AngleAxisf(angle, UnitZ).toRotationMatrix() -> [[c,-s,0],[s,c,0],[0,0,(1-c)*1*1+c]]; translate(v) adds linear * v
   const float angle = static_cast<float>(yaw_deg / 180.0 * M_PI);
-  const float c = std::cos(angle), s = std::sin(angle);
-  // AngleAxisf::toRotationMatrix() for axis (0,0,1)
-  const float R[9] = {c, -s, 0.0f, s, c, 0.0f, 0.0f, 0.0f, ((1.0f - c) * 1.0f) * 1.0f + c};
-  const float v[3] = {t[0] + corr[0], t[1] + corr[1], t[2] + corr[2]};
-  float tr[3];
+  const float cs = std::cos(angle), sn = std::sin(angle);
+  const float rot[3][3] = {{cs, -sn, 0.0f}, {sn, cs, 0.0f}, {0.0f, 0.0f, ((1.0f - cs) * 1.0f) * 1.0f + cs}};
+  float shift[3], trans[3];
   for (int r = 0; r < 3; r++)
-    tr[r] = (R[3 * r] * v[0] + R[3 * r + 1] * v[1]) + R[3 * r + 2] * v[2];  // translationExt() += linearExt() * v
-  std::vector<float> p(3 * n);
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (size_t i = 0; i < n; i++)
+    shift[r] = t[r] + corr[r];
+  for (int r = 0; r < 3; r++)
+    trans[r] = (rot[r][0] * shift[0] + rot[r][1] * shift[1]) + rot[r][2] * shift[2];
+  std::vector<float> world(xyz_in.size());
+  float lo[3], hi[3];
+  for (size_t i = 0; i < count; i++)
+  {
+    const float* src = &xyz_in[3 * i];
+    float* dst = &world[3 * i];
+    for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3))
+      dst[r] = rot[r][0] * src[0] + (rot[r][1] * src[1] + (rot[r][2] * src[2] + trans[r]));
     for (int r = 0; r < 3; r++)
     {
-      const float p0 = R[3 * r] * xyz_in[3 * i], p1 = R[3 * r + 1] * xyz_in[3 * i + 1], p2 = R[3 * r + 2] * xyz_in[3 * i + 2];
-      const float q = p0 + (p1 + (p2 + tr[r]));  // Transformer::se3
-      p[3 * i + r] = q;
-      mn[r] = std::min(mn[r], q);
-      mx[r] = std::max(mx[r], q);
+      lo[r] = i ? std::min(lo[r], dst[r]) : dst[r];
+      hi[r] = i ? std::max(hi[r], dst[r]) : dst[r];
     }
-  const float inv = 1.0f / leaf;
-  int min_b[3], div_b[3];
+  }
+  AprioriGrid grid;
+  grid.inv = 1.0f / leaf;
+  int64_t cells = 1;
   for (int r = 0; r < 3; r++)
   {
-    min_b[r] = static_cast<int>(std::floor(mn[r] * inv));
-    div_b[r] = static_cast<int>(std::floor(mx[r] * inv)) - min_b[r] + 1;
+    grid.min_b[r] = static_cast<int>(std::floor(lo[r] * grid.inv));
+    grid.div_b[r] = static_cast<int>(std::floor(hi[r] * grid.inv)) - grid.min_b[r] + 1;
+    cells *= grid.div_b[r];
   }
-  if (static_cast<int64_t>(div_b[0]) * div_b[1] * div_b[2] > 0x7fffffffll)
+  if (cells > 0x7fffffffll)
     return;  // "Leaf size is too small": PCL warns and copies the input; an apriori cloud that large is not supported here
-  std::vector<std::pair<uint32_t, uint32_t>> order(n);
-  for (size_t i = 0; i < n; i++)
+  // counting sort by cell index, 16 bits at a time (stable: points of one cell stay in input order)
+  std::vector<uint32_t> key(count), idx(count), idx2(count);
+  for (size_t i = 0; i < count; i++)
   {
-    const int i0 = static_cast<int>(std::floor(p[3 * i] * inv) - static_cast<float>(min_b[0]));
-    const int i1 = static_cast<int>(std::floor(p[3 * i + 1] * inv) - static_cast<float>(min_b[1]));
-    const int i2 = static_cast<int>(std::floor(p[3 * i + 2] * inv) - static_cast<float>(min_b[2]));
-    order[i] = {static_cast<uint32_t>(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]), static_cast<uint32_t>(i)};
+    key[i] = grid.cell(&world[3 * i]);
+    idx[i] = static_cast<uint32_t>(i);
   }
-  std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-  for (size_t a = 0; a < n;)
+  for (int pass = 0; pass < 2; pass++)
   {
-    size_t b = a;
-    float sum[3] = {0, 0, 0};
-    while (b < n && order[b].first == order[a].first)
-    {
-      for (int r = 0; r < 3; r++)
-        sum[r] += p[3 * order[b].second + r];
-      b++;
-    }
+    std::vector<uint32_t> start(65537, 0u);
+    const int sh = 16 * pass;
+    for (size_t i = 0; i < count; i++)
+      start[((key[idx[i]] >> sh) & 0xffffu) + 1]++;
+    for (size_t d = 0; d < 65536; d++)
+      start[d + 1] += start[d];
+    for (size_t i = 0; i < count; i++)
+      idx2[start[(key[idx[i]] >> sh) & 0xffffu]++] = idx[i];
+    idx.swap(idx2);
+  }
+  size_t run_begin = 0;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (size_t i = 0; i < count; i++)
+  {
+    const float* q = &world[3 * idx[i]];
     for (int r = 0; r < 3; r++)
-      out.push_back(sum[r] / static_cast<float>(b - a));
-    a = b;
+      acc[r] += q[r];
+    if (i + 1 == count || key[idx[i + 1]] != key[idx[i]])
+    {
+      const float members = static_cast<float>(i + 1 - run_begin);
+      for (int r = 0; r < 3; r++)
+      {
+        out.push_back(acc[r] / members);
+        acc[r] = 0.0f;
+      }
+      run_begin = i + 1;
+    }
   }
 }
 

@@ -361,3 +361,16 @@ def mask_layout(lib, image, w: int, h: int, pixel_shift_by_row=None, mangle: boo
     if st != capi.OK:
         raise RuntimeError(f"vofod_mask_layout: status {st}")
     return out
+
+
+def check_sensor_params(lib, scan: ScanData, lut_directions, lut_offsets=None, mask=None):
+    """check_sensor_params (vofod_nodelet.cpp:1869-1917): (params_ok, checked) for a host-resident organised scan"""
+    d = np.ascontiguousarray(lut_directions, dtype=np.float32).reshape(-1)
+    o = None if lut_offsets is None else np.ascontiguousarray(lut_offsets, dtype=np.float32).reshape(-1)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+    cs = scan.as_c()
+    checked = C.c_int32(0)
+    st = lib.check_sensor_params(C.byref(cs), capi.ptr(d), None if o is None else capi.ptr(o), None if m is None else capi.ptr(m), C.byref(checked))
+    if st not in (capi.OK, capi.ERR_SIZE_MISMATCH):
+        raise VofodError(st, "vofod_check_sensor_params")
+    return st == capi.OK, bool(checked.value)
