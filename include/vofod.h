@@ -140,6 +140,12 @@ typedef struct vofod_point_xyzr {
   uint32_t range;
 } vofod_point_xyzr;
 
+/* pcl::PointXYZI payload of the debug clouds (voxel_map.h pt_t) */
+typedef struct vofod_point_xyzi {
+  float x, y, z;
+  float intensity;
+} vofod_point_xyzi;
+
 /* vofod/Detection (msgs/Detection.msg:1-12), filled as vofod_nodelet.cpp:972-985 */
 typedef struct vofod_detection {
   uint32_t id;
@@ -227,6 +233,12 @@ int vofod_load_apriori(vofod_handle* h, const float* xyz, size_t n);
  * voxel size -> vofod_load_apriori.  Init-time host work in the reference and here. */
 int vofod_ingest_apriori(vofod_handle* h, const char* filename, const float tf_xyz[3], double yaw_deg, const float sim_correction[3],
                          size_t* n_loaded, size_t* n_voxels);
+
+/* VoxelMap::voxelsAsPC (voxel_map.cpp:157-183): the voxels with ((value > threshold) == greater_than) of map `which` as
+ * world-frame centres + value, in the reference's order (x outer, y, z inner).  The nodelet's debug clouds
+ * (vofod_nodelet.cpp:999-1013): background = (VOFOD_MAP_VOXELS, new_obstacles, 1), sure air = (VOFOD_MAP_VOXELS, frontiers, 0).
+ * VOFOD_ERR_CAPACITY: *n_out holds the required number of points. */
+int vofod_voxels_as_pc(vofod_handle* h, int which, float threshold, int greater_than, vofod_point_xyzi* out, size_t cap, size_t* n_out);
 
 /* processMsg(sensor_msgs::Range) :581-613 (row N4 of SURVEY 8f): the height range-finder marks the voxel it hits as
  * background-ish: p = tf * (range, 0, 0); if inLimits(p): map(p) = (map(p) + voxel_map/scores/point) / 2.0.
@@ -347,6 +359,43 @@ int vofod_check_sensor_params(const vofod_scan* scan, const float* lut_direction
  * launches.  Returns the number of distinct kernels.  No-ops in the oracle. */
 int vofod_profile_enable(vofod_handle* h, int on);
 size_t vofod_profile_read(vofod_handle* h, char* names, double* ms, uint64_t* calls, size_t cap);
+
+/* ------------------------------------------------- outgoing messages (product library only)
+ *
+ * The nodelet's publications in the ROS 1 wire format (little endian; strings / arrays carry a uint32 length; a
+ * std_msgs/Header is seq, stamp.sec, stamp.nsec, frame_id), for hosts without ROS: vofod/Detections
+ * (msgs/Detections.msg + Detection.msg:1-12, vofod_nodelet.cpp:968-988), vofod/Status (msgs/Status.msg, :1379-1385),
+ * vofod/ProfilingInfo (msgs/ProfilingInfo.msg, :2178-2201; event_type 1 = start, 2 = end).  buf may be NULL to ask for the
+ * size; VOFOD_ERR_CAPACITY when cap is too small (*n_bytes = bytes needed). */
+typedef struct vofod_msg_header {
+  uint32_t seq;
+  uint32_t stamp_sec, stamp_nsec;
+  const char* frame_id; /* world frame (m_world_frame_id) */
+} vofod_msg_header;
+int vofod_serialize_detections(const vofod_msg_header* header, const vofod_detection* dets, size_t n, uint8_t* buf, size_t cap, size_t* n_bytes);
+int vofod_serialize_status(const vofod_msg_header* header, int detection_enabled, int detection_active, uint8_t* buf, size_t cap, size_t* n_bytes);
+int vofod_serialize_profiling_info(uint32_t stamp_sec, uint32_t stamp_nsec, uint32_t routine_id, uint64_t event_sequence, uint8_t event_type, uint8_t* buf, size_t cap,
+                                   size_t* n_bytes);
+
+/* ------------------------------------------------- batched mode: the collective (product library only)
+ *
+ * one process per GPU runs vofod_process_batch / vofod_batch_submit+collect on its own block of frames; the only
+ * exchange is one all-gather of fixed-size slots - d_max 128-byte vofod_detection records (msgs/Detection.msg:1-12 + frame)
+ * and a count word per frame - with RCCL over xGMI.  The communicator is RCCL's: one rank asks for an id
+ * (ncclGetUniqueId), the host program ships its 128 bytes to the other ranks by whatever means it has (MPI, a socket,
+ * torch.distributed), every rank creates its vofod_comm from it (ncclCommInitRank).  RCCL is loaded at run time.
+ * The CPU oracle does not export these (it has no device to gather on). */
+#define VOFOD_COMM_ID_BYTES 128
+typedef struct vofod_comm vofod_comm;
+int vofod_comm_unique_id(uint8_t id[VOFOD_COMM_ID_BYTES]);
+int vofod_comm_create(const uint8_t id[VOFOD_COMM_ID_BYTES], int32_t rank, int32_t n_ranks, int32_t device, vofod_comm** out);
+void vofod_comm_destroy(vofod_comm* comm);
+const char* vofod_comm_last_error(vofod_comm* comm);
+/* local: this rank's detections in frame order (what vofod_process_batch / vofod_batch_collect returned), n_per_frame: their
+ * count per frame.  all: n_ranks * frames_per_rank * d_max records, slot (rank, frame) holds min(count, d_max) records;
+ * all_counts: n_ranks * frames_per_rank counts (a count above d_max tells that the slot was truncated). */
+int vofod_allgather_detections(vofod_comm* comm, const vofod_detection* local, const uint32_t* n_per_frame, size_t frames_per_rank, size_t d_max, vofod_detection* all,
+                               uint32_t* all_counts);
 
 #ifdef __cplusplus
 }

@@ -1195,6 +1195,35 @@ int ORACLE_API(mask_layout)(const uint8_t* image, int32_t w, int32_t hh, const i
   return VOFOD_OK;
 }
 
+// VoxelMap::voxelsAsPC (voxel_map.cpp:157-183), loop for loop
+int ORACLE_API(voxels_as_pc)(vofod_handle* h, int which, float threshold, int greater_than, vofod_point_xyzi* out, size_t cap, size_t* n_out)
+{
+  if (!h || !n_out || (cap && !out))
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  vo::VoxelMap* m = which == VOFOD_MAP_VOXELS ? &h->vmap : which == VOFOD_MAP_FLAGS ? &h->vflags : which == VOFOD_MAP_RAYCAST ? &h->vraycast : nullptr;
+  if (!m)
+    return VOFOD_ERR_INVALID_ARG;
+  size_t n = 0;
+  for (int x_it = 0; x_it < m->sx; x_it++)
+    for (int y_it = 0; y_it < m->sy; y_it++)
+      for (int z_it = 0; z_it < m->sz; z_it++)
+      {
+        const float mapval = m->data[static_cast<size_t>(x_it) + static_cast<size_t>(y_it) * m->sx + static_cast<size_t>(z_it) * m->sx * m->sy];
+        if ((mapval > threshold) == (greater_than != 0))
+        {
+          if (n < cap)
+          {
+            const auto c = m->idxToCoord(x_it, y_it, z_it);
+            out[n] = vofod_point_xyzi{c[0], c[1], c[2], mapval};
+          }
+          n++;
+        }
+      }
+  *n_out = n;
+  return n > cap ? VOFOD_ERR_CAPACITY : VOFOD_OK;
+}
+
 // check_sensor_params (vofod_nodelet.cpp:1869-1917), statement by statement: rows outer, columns inner, the first pixel with
 // mask != 0 and range != 0 decides.  Eigen: (a - b).normalized() = v / sqrt(v.squaredNorm()), norm() = sqrt(x*x + y*y + z*z).
 int ORACLE_API(check_sensor_params)(const vofod_scan* scan, const float* lut_directions, const float* lut_offsets, const uint8_t* mask, int32_t* checked)

@@ -326,3 +326,53 @@ def test_calls_that_would_race_a_batch_in_flight_are_refused(oracle, hip):
     dh = dev.process_scan(scans[0], tfs[0])
     assert_detections_equal(dr, dh)
     np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+
+
+def test_cabi_collective_single_rank(hip):
+    """vofod_comm_* / vofod_allgather_detections (RCCL behind the C-ABI): a one-rank communicator on the GPU returns the
+    rank's own slots - records in frame order, truncated at d_max, true counts kept.  (More ranks need more GPUs: the
+    multi-rank layout is covered on the CPU by tests/test_dist_gloo.py through the same packing.)"""
+    from vofod_amd import dist as vdist
+
+    comm = vdist.CabiComm(hip, rank=0, world=1, device=0)
+    rng = np.random.default_rng(3)
+    per = np.uint32([0, 2, 0, 5, 1, 0, 20, 0])
+    dets = np.zeros(int(per.sum()), dtype=capi.DETECTION)
+    dets["id"] = np.arange(len(dets))
+    dets["n_points"] = rng.integers(1, 50, len(dets))
+    dets["confidence"] = rng.random(len(dets))
+    dets["position"] = rng.normal(size=(len(dets), 3))
+    frame_of = np.repeat(np.arange(len(per)), per)
+    dets["frame"] = frame_of
+    out, cnt = comm.allgather(dets, per, d_max=16)
+    assert out.shape == (1, len(per), 16)
+    np.testing.assert_array_equal(cnt[0], per)
+    start = np.cumsum(per) - per
+    for f in range(len(per)):
+        m = min(int(per[f]), 16)
+        np.testing.assert_array_equal(out[0, f, :m], dets[start[f] : start[f] + m])
+        assert not out[0, f, m:]["n_points"].any()
+    out2, cnt2 = comm.allgather(np.zeros(0, dtype=capi.DETECTION), np.zeros(4, np.uint32))  # nothing detected anywhere
+    assert not cnt2.any() and out2.shape == (1, 4, 16)
+    comm.close()
+
+
+def test_voxels_as_pc_debug_clouds(oracle, hip):
+    """row N4: VoxelMap::voxelsAsPC (voxel_map.cpp:157-183) - background cloud (map > new_obstacles) and sure-air cloud
+    (!(map > frontiers)) of a warmed map, in the reference's x-outer / z-inner order, bit for bit"""
+    ref, dev = make_pair(oracle, hip, "os1-16", 0.5)
+    scene = synth.make_scene(6, n_targets=1)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    for s in synth.scan_sequence(scene, "os1-16", 3, seed0=5):
+        ref.process_scan(s.scan, s.tf)
+        dev.process_scan(s.scan, s.tf)
+    np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+    for thr, gt in ((float(dev.dp.voxel_map__thresholds__new_obstacles), True), (float(dev.dp.voxel_map__thresholds__frontiers), False), (1e9, True)):
+        a, b = ref.voxels_as_pc(thr, gt), dev.voxels_as_pc(thr, gt)
+        assert a.shape == b.shape
+        np.testing.assert_array_equal(b.view(np.uint32), a.view(np.uint32))
+    bg = dev.voxels_as_pc(float(dev.dp.voxel_map__thresholds__new_obstacles), True)
+    assert len(bg) > 100 and (bg[:, 3] > dev.dp.voxel_map__thresholds__new_obstacles).all()
+    # x outer, y, z inner: x never decreases
+    assert (np.diff(bg[:, 0]) >= 0).all()

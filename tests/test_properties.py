@@ -93,3 +93,43 @@ def test_sensor_helpers_of_the_product_match_the_oracle(oracle):
         sc = ScanData(x=np.ascontiguousarray(p[:, 0]), y=np.ascontiguousarray(p[:, 1]), z=np.ascontiguousarray(p[:, 2]), width=w, height=h,
                       intensity=np.zeros(h * w, np.float32), range=r, stride_bytes=4)
         assert check_sensor_params(oracle, sc, lut, mask=m) == check_sensor_params(hip, sc, lut, mask=m)
+
+
+def test_message_serialisation_byte_layout():
+    """row N3: vofod/Detections, vofod/Status, vofod/ProfilingInfo in the ROS 1 wire format - expected bytes built by hand
+    from msgs/*.msg (little endian, uint32 length prefixes; Header = seq, stamp.sec, stamp.nsec, frame_id)"""
+    import ctypes as C
+    import struct
+
+    import vofod_amd
+    from vofod_amd import capi
+
+    try:
+        hip = vofod_amd.library()
+    except (ImportError, OSError) as e:
+        pytest.skip(f"product library not loadable here: {e}")
+    hdr = capi.MsgHeader(7, 1700000000, 250000000, b"uav1/world_origin")
+    hdr_bytes = struct.pack("<III", 7, 1700000000, 250000000) + struct.pack("<I", 17) + b"uav1/world_origin"
+    dets = np.zeros(2, dtype=capi.DETECTION)
+    dets["id"] = [41, 42]
+    dets["n_points"] = [9, 3]
+    dets["confidence"] = [0.75, 0.5]
+    dets["detection_probability"] = [0.9, 0.1]
+    dets["position"] = [[1.0, 2.0, 3.0], [-4.0, 5.5, 6.25]]
+    dets["covariance"][:, 0] = dets["covariance"][:, 4] = dets["covariance"][:, 8] = [0.3, 0.6]
+    want = hdr_bytes + struct.pack("<I", 2)
+    for d in dets:
+        want += struct.pack("<I", int(d["id"])) + struct.pack("<d", float(d["confidence"])) + struct.pack("<Q", int(d["n_points"]))
+        want += struct.pack("<3d", *d["position"]) + struct.pack("<9d", *d["covariance"]) + struct.pack("<d", float(d["detection_probability"]))
+    n = C.c_size_t(0)
+    assert hip.serialize_detections(C.byref(hdr), capi.ptr(dets), 2, None, 0, C.byref(n)) == capi.ERR_CAPACITY and n.value == len(want)
+    buf = np.zeros(n.value, dtype=np.uint8)
+    assert hip.serialize_detections(C.byref(hdr), capi.ptr(dets), 2, capi.ptr(buf), buf.size, C.byref(n)) == capi.OK
+    assert buf.tobytes() == want
+    # Detection.msg: 4 + 8 + 8 + 24 + 72 + 8 bytes per record
+    assert len(want) == len(hdr_bytes) + 4 + 2 * 124
+    buf = np.zeros(64, dtype=np.uint8)
+    assert hip.serialize_status(C.byref(hdr), 1, 0, capi.ptr(buf), buf.size, C.byref(n)) == capi.OK
+    assert buf[: n.value].tobytes() == hdr_bytes + bytes([1, 0])
+    assert hip.serialize_profiling_info(12, 34, 5, 6, 2, capi.ptr(buf), buf.size, C.byref(n)) == capi.OK
+    assert buf[: n.value].tobytes() == struct.pack("<IIIQB", 12, 34, 5, 6, 2) and n.value == 21

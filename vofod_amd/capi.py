@@ -229,6 +229,15 @@ _SIGS = {
     "ouster_lut": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mask_layout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "check_sensor_params": (C.c_int, [_P(Scan), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int32)]),
+    "serialize_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "serialize_status": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "serialize_profiling_info": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint8, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "comm_unique_id": (C.c_int, [C.c_void_p]),
+    "comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _P(C.c_void_p)]),
+    "comm_destroy": (None, [C.c_void_p]),
+    "comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "allgather_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "voxels_as_pc": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "update_ground": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "read_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "write_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
@@ -250,6 +259,15 @@ _SIGS = {
 }
 
 
+# entry points only the product library has to export (include/vofod.h says so)
+PRODUCT_ONLY = ("comm_unique_id", "comm_create", "comm_destroy", "comm_last_error", "allgather_detections", "serialize_detections", "serialize_status",
+                "serialize_profiling_info")
+
+
+class MsgHeader(C.Structure):
+    _fields_ = [("seq", C.c_uint32), ("stamp_sec", C.c_uint32), ("stamp_nsec", C.c_uint32), ("frame_id", C.c_char_p)]
+
+
 class Library:
     """A loaded implementation of include/vofod.h under a symbol prefix."""
 
@@ -263,6 +281,8 @@ class Library:
             try:
                 fn = getattr(self.cdll, sym)
             except AttributeError:
+                if name in PRODUCT_ONLY and prefix != "vofod_":
+                    continue  # the collective of the batched mode: the CPU oracle has no device to gather on
                 missing.append(sym)
                 continue
             res, args = _SIGS[name]

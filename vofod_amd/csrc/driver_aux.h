@@ -390,6 +390,37 @@ int copy_grid_out(vofod_handle* h, Workspace& ws, const GridParams& g, const Fra
 }  // namespace
 
 // =============================================================================== extern "C"
+namespace
+{
+struct WireOut
+{
+  uint8_t* buf;
+  size_t cap, n = 0;
+  template <class T>
+  void put(const T& v)
+  {
+    if (buf && n + sizeof(T) <= cap)
+      std::memcpy(buf + n, &v, sizeof(T));
+    n += sizeof(T);
+  }
+  void str(const char* s)
+  {
+    const uint32_t len = s ? static_cast<uint32_t>(std::strlen(s)) : 0u;
+    put(len);
+    if (buf && n + len <= cap)
+      std::memcpy(buf + n, s, len);
+    n += len;
+  }
+  void header(const vofod_msg_header* h)
+  {
+    put(h->seq);
+    put(h->stamp_sec);
+    put(h->stamp_nsec);
+    str(h->frame_id);
+  }
+};
+}  // namespace
+
 extern "C" {
 
 void vofod_default_params(vofod_static_params* sp, vofod_dyn_params* dp)
@@ -904,6 +935,40 @@ int vofod_read_map(vofod_handle* h, int which, float* dst, size_t n)
   return VOFOD_OK;
 }
 
+int vofod_voxels_as_pc(vofod_handle* h, int which, float threshold, int greater_than, vofod_point_xyzi* out, size_t cap, size_t* n_out)
+{
+  if (!h || !n_out || (cap && !out))
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  const float* m = pick_map(h, which);
+  if (!m)
+    return VOFOD_ERR_INVALID_ARG;
+  *n_out = 0;
+  vr::SepState& s = h->sep;
+  const uint32_t ncol = static_cast<uint32_t>(h->mg.sx) * h->mg.sy;
+  int r;
+  if ((r = sep_ensure_words(h, ncol + 2)) != VOFOD_OK || (r = sep_ensure_pts(h, std::max<size_t>(1 << 16, ncol))) != VOFOD_OK)
+    return r;
+  KLAUNCH(h, vr::k_col_count_thr, dim3((ncol + 255) / 256), dim3(256), h->mg, m, threshold, greater_than, s.d_tpop);
+  if ((r = gscan(h, s.d_tpop, ncol, s.d_tprefix, s.d_bsum, s.d_small)) != VOFOD_OK)
+    return r;
+  HIPCHK(hipMemcpyAsync(s.h_small, s.d_small, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const uint32_t P = s.h_small[0];
+  *n_out = P;
+  if (P > cap)
+    return VOFOD_ERR_CAPACITY;  // n_out holds the required size
+  if (P == 0)
+    return VOFOD_OK;
+  if ((r = ensure_boxstage(h, static_cast<size_t>(P) * 4)) != VOFOD_OK)
+    return r;
+  KLAUNCH(h, vr::k_col_emit_xyzi, dim3((ncol + 255) / 256), dim3(256), h->mg, m, threshold, greater_than, s.d_tprefix, P, reinterpret_cast<float4*>(h->d_boxstage));
+  HIPCHK(hipMemcpyAsync(out, h->d_boxstage, sizeof(vofod_point_xyzi) * P, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VOFOD_OK;
+}
+
 int vofod_update_ground(vofod_handle* h, float range, float min_range, float max_range, const float tf[12])
 {
   if (!h || !tf)
@@ -1266,6 +1331,62 @@ int vofod_ingest_apriori(vofod_handle* h, const char* filename, const float tf_x
   if (n_voxels)
     *n_voxels = cent.size() / 3;
   return vofod_load_apriori(h, cent.data(), cent.size() / 3);
+}
+
+// ---- row N3: the nodelet's outgoing messages in the ROS 1 wire format (little endian, strings and arrays prefixed with a
+// uint32 length; std_msgs/Header = seq, stamp.sec, stamp.nsec, frame_id).  A ROS-free host (examples/vofod_replay.cpp)
+// writes exactly the bytes a subscriber of the reference's topics receives.
+
+// vofod/Detections (msgs/Detections.msg, msgs/Detection.msg:1-12; filled at vofod_nodelet.cpp:968-988)
+int vofod_serialize_detections(const vofod_msg_header* header, const vofod_detection* dets, size_t n, uint8_t* buf, size_t cap, size_t* n_bytes)
+{
+  if (!header || (n && !dets) || !n_bytes)
+    return VOFOD_ERR_INVALID_ARG;
+  WireOut w{buf, cap};
+  w.header(header);
+  w.put(static_cast<uint32_t>(n));
+  for (size_t i = 0; i < n; i++)
+  {
+    const vofod_detection& d = dets[i];
+    w.put(d.id);
+    w.put(d.confidence);
+    w.put(d.n_points);
+    for (int a = 0; a < 3; a++)
+      w.put(d.position[a]);  // geometry_msgs/Point
+    for (int a = 0; a < 9; a++)
+      w.put(d.covariance[a]);
+    w.put(d.detection_probability);
+  }
+  *n_bytes = w.n;
+  return w.n > cap ? VOFOD_ERR_CAPACITY : VOFOD_OK;
+}
+
+// vofod/Status (msgs/Status.msg; vofod_nodelet.cpp:1379-1385)
+int vofod_serialize_status(const vofod_msg_header* header, int detection_enabled, int detection_active, uint8_t* buf, size_t cap, size_t* n_bytes)
+{
+  if (!header || !n_bytes)
+    return VOFOD_ERR_INVALID_ARG;
+  WireOut w{buf, cap};
+  w.header(header);
+  w.put(static_cast<uint8_t>(detection_enabled ? 1 : 0));
+  w.put(static_cast<uint8_t>(detection_active ? 1 : 0));
+  *n_bytes = w.n;
+  return w.n > cap ? VOFOD_ERR_CAPACITY : VOFOD_OK;
+}
+
+// vofod/ProfilingInfo (msgs/ProfilingInfo.msg; vofod_nodelet.cpp:2178-2201)
+int vofod_serialize_profiling_info(uint32_t stamp_sec, uint32_t stamp_nsec, uint32_t routine_id, uint64_t event_sequence, uint8_t event_type, uint8_t* buf, size_t cap, size_t* n_bytes)
+{
+  if (!n_bytes)
+    return VOFOD_ERR_INVALID_ARG;
+  WireOut w{buf, cap};
+  w.put(stamp_sec);
+  w.put(stamp_nsec);
+  w.put(routine_id);
+  w.put(event_sequence);
+  w.put(event_type);
+  *n_bytes = w.n;
+  return w.n > cap ? VOFOD_ERR_CAPACITY : VOFOD_OK;
 }
 
 int vofod_profile_enable(vofod_handle* h, int on)

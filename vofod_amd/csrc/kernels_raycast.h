@@ -290,6 +290,51 @@ __global__ __launch_bounds__(256) void k_col_count(const MapGeom mg, const unsig
   colcount_t[x * mg.sy + y] = c;
 }
 
+// voxelsAsPC (voxel_map.cpp:157-183): the debug clouds of the nodelet (background: map > new_obstacles; sure air: !(map >
+// frontiers), vofod_nodelet.cpp:999-1013) in the reference's order, x outer / y / z inner, as world coordinates + map value.
+// Same column walk as above, on the float map itself: ((m > threshold) == greater_than) needs no occupancy image.
+__global__ __launch_bounds__(256) void k_col_count_thr(const MapGeom mg, const float* __restrict__ map, float threshold, int greater_than, uint32_t* __restrict__ colcount_t)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ncol = static_cast<uint32_t>(mg.sx) * mg.sy;
+  if (t >= ncol)
+    return;
+  const uint32_t x = t % mg.sx, y = t / mg.sx;
+  const uint64_t plane = static_cast<uint64_t>(mg.sx) * mg.sy;
+  uint32_t c = 0;
+  uint64_t li = t;
+  for (int z = 0; z < mg.sz; z++, li += plane)
+    c += ((map[li] > threshold) == (greater_than != 0)) ? 1u : 0u;
+  colcount_t[x * mg.sy + y] = c;
+}
+
+__global__ __launch_bounds__(256) void k_col_emit_xyzi(const MapGeom mg, const float* __restrict__ map, float threshold, int greater_than, const uint32_t* __restrict__ colbase_t,
+                                                       uint32_t cap, float4* __restrict__ out)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ncol = static_cast<uint32_t>(mg.sx) * mg.sy;
+  if (t >= ncol)
+    return;
+  const uint32_t x = t % mg.sx, y = t / mg.sx;
+  const uint64_t plane = static_cast<uint64_t>(mg.sx) * mg.sy;
+  uint32_t pos = colbase_t[x * mg.sy + y];
+  if (colbase_t[x * mg.sy + y + 1] == pos)
+    return;  // empty column
+  const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(x), 0.5f), mg.vs), mg.off[0]);  // idxToCoord voxel_map.cpp:610-613
+  const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(y), 0.5f), mg.vs), mg.off[1]);
+  uint64_t li = t;
+  for (int z = 0; z < mg.sz; z++, li += plane)
+  {
+    const float m = map[li];
+    if ((m > threshold) == (greater_than != 0))
+    {
+      if (pos < cap)
+        out[pos] = make_float4(cx, cy, __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(z), 0.5f), mg.vs), mg.off[2]), m);
+      pos++;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_col_emit(const MapGeom mg, const float* __restrict__ map, const unsigned long long* __restrict__ mapbits,
                                                   const uint32_t* __restrict__ colbase_t, float thr_sure, float* __restrict__ px, float* __restrict__ py,
                                                   float* __restrict__ pz, float* __restrict__ pi, uint32_t* __restrict__ sure)

@@ -2266,3 +2266,4 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
 }  // namespace
 
 #include "driver_aux.h"
+#include "collective.h"

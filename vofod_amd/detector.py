@@ -150,6 +150,17 @@ class VoFOD:
         sx, sy, sz = self.map_size
         return out.reshape(sz, sy, sx)
 
+    def voxels_as_pc(self, threshold: float, greater_than: bool = True, which: int = capi.MAP_VOXELS) -> np.ndarray:
+        """VoxelMap::voxelsAsPC (voxel_map.cpp:157-183): [n, 4] float32 world centres + map value, x outer / y / z inner"""
+        n = C.c_size_t(0)
+        st = self.lib.voxels_as_pc(self.h, which, float(threshold), int(bool(greater_than)), None, 0, C.byref(n))
+        if st not in (capi.OK, capi.ERR_CAPACITY):
+            self._check(st, "vofod_voxels_as_pc")
+        out = np.zeros((n.value, 4), dtype=np.float32)
+        if n.value:
+            self._check(self.lib.voxels_as_pc(self.h, which, float(threshold), int(bool(greater_than)), capi.ptr(out), n.value, C.byref(n)), "vofod_voxels_as_pc")
+        return out
+
     def write_map(self, which: int, arr: np.ndarray):
         a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
         self._check(self.lib.write_map(self.h, which, capi.ptr(a), a.size), "vofod_write_map")

@@ -67,3 +67,57 @@ def allgather_detections(local, gathered=None):
         # concatenated layout [world * frames, ...] is what every backend accepts; same memory as [world, frames, ...]
         dist.all_gather_into_tensor(gathered.view((world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous())
     return gathered
+
+
+class CabiComm:
+    """The same all-gather through the product's C-ABI (vofod_comm_* / vofod_allgather_detections: RCCL called from
+    libvofod_hip.so, what a C++ nodelet host links against).  `bootstrap(id_bytes) -> id_bytes` ships rank 0's 128-byte
+    RCCL id to every rank (torch.distributed broadcast, MPI, a socket ...); with one rank nothing is shipped."""
+
+    def __init__(self, lib: capi.Library, rank: int, world: int, device: int, bootstrap=None):
+        import ctypes as C
+
+        self.lib, self.rank, self.world = lib, rank, world
+        ident = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            st = lib.comm_unique_id(capi.ptr(ident))
+            if st != capi.OK:
+                raise RuntimeError(f"vofod_comm_unique_id: status {st}: {lib.comm_last_error(None).decode()}")
+        if world > 1:
+            if bootstrap is None:
+                raise ValueError("more than one rank needs a bootstrap function for the communicator id")
+            ident = np.ascontiguousarray(bootstrap(ident), dtype=np.uint8)
+        self.h = C.c_void_p()
+        st = lib.comm_create(capi.ptr(ident), rank, world, device, C.byref(self.h))
+        if st != capi.OK:
+            raise RuntimeError(f"vofod_comm_create: status {st}: {lib.comm_last_error(None).decode()}")
+
+    def allgather(self, dets: np.ndarray, per_frame: np.ndarray, d_max: int = D_MAX):
+        """-> (records [world, frames, d_max] of capi.DETECTION, counts [world, frames])"""
+        per = np.ascontiguousarray(per_frame, dtype=np.uint32)
+        loc = np.ascontiguousarray(dets, dtype=capi.DETECTION)
+        n = len(per)
+        out = np.zeros((self.world, n, d_max), dtype=capi.DETECTION)
+        cnt = np.zeros((self.world, n), dtype=np.uint32)
+        st = self.lib.allgather_detections(self.h, capi.ptr(loc) if len(loc) else None, capi.ptr(per), n, d_max, capi.ptr(out), capi.ptr(cnt))
+        if st != capi.OK:
+            raise RuntimeError(f"vofod_allgather_detections: status {st}: {self.lib.comm_last_error(self.h).decode()}")
+        return out, cnt
+
+    def close(self):
+        if self.h:
+            self.lib.comm_destroy(self.h)
+            self.h = None
+
+
+def torch_bootstrap(device):
+    """bootstrap for CabiComm over an initialised torch.distributed process group"""
+    import torch
+    import torch.distributed as dist
+
+    def ship(ident: np.ndarray) -> np.ndarray:
+        t = torch.from_numpy(ident.copy()).to(device)
+        dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
+    return ship
