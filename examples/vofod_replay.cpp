@@ -169,7 +169,8 @@ int main(int argc, char** argv)
   });
 
   // ---- main role: one cloud per iteration
-  size_t total_det = 0;
+  size_t total_det = 0, det_on_target = 0, det_off_target = 0, msg_bytes = 0;
+  std::vector<uint8_t> msg_buf;
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < n_scans; k++)
   {
@@ -213,9 +214,26 @@ int main(int argc, char** argv)
     if (!raycast_running.exchange(true))  // :953-957
       raycast_threads.emplace_back(raycast_role, c);
     for (size_t i = 0; i < std::min<size_t>(n_det, 64); i++)
+    {
       std::printf("scan %3d detection id %u conf %.3f at (%.2f, %.2f, %.2f), %llu points\n", k, dets[i].id, dets[i].confidence, dets[i].position[0], dets[i].position[1],
                   dets[i].position[2], static_cast<unsigned long long>(dets[i].n_points));
+      // result check: the only thing flying in this world is the 0.5 m cube (OBB centre of its visible faces: within 0.6 m)
+      const double e[3] = {dets[i].position[0] - 6 * std::cos(a), dets[i].position[1] - 6 * std::sin(a), dets[i].position[2] - 3.0};
+      (std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) <= 0.6 ? det_on_target : det_off_target)++;
+    }
     total_det += n_det;
+    {
+      // what m_pub_detections / m_pub_status would carry (:968-989, :1379-1385), byte for byte in the ROS 1 wire format
+      const vofod_msg_header mh{static_cast<uint32_t>(k), static_cast<uint32_t>(k / 10), static_cast<uint32_t>((k % 10) * 100000000), "world_origin"};
+      size_t nb = 0;
+      msg_buf.resize(4096);
+      if (vofod_serialize_detections(&mh, dets, std::min<size_t>(n_det, 64), msg_buf.data(), msg_buf.size(), &nb) == VOFOD_OK)
+        msg_bytes += nb;
+      vofod_status_info st_now;
+      vofod_get_status(h, &st_now);
+      if (vofod_serialize_status(&mh, 1, st_now.background_pts_sufficient && st_now.sure_background_sufficient, msg_buf.data(), msg_buf.size(), &nb) == VOFOD_OK)
+        msg_bytes += nb;
+    }
     if (period_ms > 0)
       std::this_thread::sleep_for(std::chrono::milliseconds(period_ms));
   }
@@ -228,6 +246,7 @@ int main(int argc, char** argv)
   vofod_get_status(h, &si);
   std::printf("done: %d scans in %.3f s (%.1f scans/s incl. synthesis), detections %zu, detection_its %d, raycasts %d (timeouts %d), sepclusters passes %d\n", n_scans, secs, n_scans / secs,
               total_det, si.detection_its, n_raycasts.load(), n_raycast_timeouts.load(), n_sep.load());
+  std::printf("check: %zu detections on the flying target, %zu elsewhere; %zu message bytes serialised\n", det_on_target, det_off_target, msg_bytes);
   vofod_destroy(h);
-  return 0;
+  return det_off_target > det_on_target ? 3 : 0;  // (the target is found in most scans once the map has settled; strays are rare)
 }

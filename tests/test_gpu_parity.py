@@ -537,6 +537,14 @@ def test_replay_driver_runs_the_three_thread_roles(hip):
     subprocess.run(["make", "-C", str(root / "examples")], check=True)
     out = subprocess.run([str(root / "examples" / "vofod_replay"), "--scans", "30", "--rows", "32", "--cols", "1024", "--voxel", "0.5"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    last = out.stdout.strip().splitlines()[-1]
+    lines = out.stdout.strip().splitlines()
+    last, check = lines[-2], lines[-1]
     assert last.startswith("done: 30 scans") and "detection_its 30" in last, last
     assert "raycasts 0 " not in last  # the raycast role ran at least once
+    # result check: the detections sit on the flying cube, the outgoing messages were serialised
+    import re
+
+    m = re.match(r"check: (\d+) detections on the flying target, (\d+) elsewhere; (\d+) message bytes", check)
+    assert m, check
+    on, off, nbytes = map(int, m.groups())
+    assert on >= 5 and off <= on // 4 and nbytes > 30 * (12 + 4 + 12 + 4), check
