@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--map-warm-scans", type=int, default=96)
     ap.add_argument("--cpu-baseline-scans", type=int, default=512, help="scans timed through the CPU oracle (0 disables); ~10 s of single-thread CPU work")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (1..4); their kernel chains overlap on the device")
+    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (1..4); their kernel chains run on streams of their own and overlap on the device")
+    ap.add_argument("--collective", choices=("torch", "cabi"), default="torch", help="N > 1: all-gather through torch.distributed (RCCL / gloo) or through the product's C-ABI (vofod_allgather_detections: RCCL from libvofod_hip.so)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --frames per GPU per step; strong: --frames in total per step, split over the GPUs (configs[3]: 256 scans over 8 GPUs)")
@@ -112,9 +113,14 @@ def main():
     rec_all = torch.zeros((world, F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
     rec_hosts = [torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64).pin_memory() for _ in range(2)]  # the async copy of one step is not overwritten by the next
     pub_count = [0]
+    cabi_comm = None
+    if world > 1 and args.collective == "cabi":
+        cabi_comm = vdist.CabiComm(lib, rank, world, local_rank, bootstrap=vdist.torch_bootstrap(cdev))
 
     def publish(dets, per):
-        if world > 1:
+        if cabi_comm is not None:
+            cabi_comm.allgather(dets, per)
+        elif world > 1:
             rec_host = rec_hosts[pub_count[0] & 1]
             pub_count[0] += 1
             vdist.pack_detections(dets, per, out=rec_host.numpy())
@@ -182,7 +188,7 @@ def main():
                 "map_voxels": det.n_voxels,
                 "map_warm_scans": args.map_warm_scans,
                 "detections_per_step": n_det / args.steps,
-                "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight (own streams below 200 frames per batch, one stream above: the kernels then fill the chip)",
+                "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight on streams of their own; classification tail on the device",
             },
         }
         # single-stream (stateful, sequential) latency of the same scan shape

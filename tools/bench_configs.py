@@ -94,7 +94,9 @@ def run(name, sensor, vs, apriori, n_warm, n_timed):
         "kernels": {k: {"avg_us": round(v["avg_us"], 1), "launches": v["launches"]} for k, v in kern.items()},
     }
     # HBM-bound sweeps: algorithmic bytes / time
-    for k, b in (("k_ray_sweep", 12.0 * M), ("k_mapbits", 4.0 * M + M / 8.0)):
+    # k_ray_sweep reads flags[i] and ray[i] of every voxel (8 bytes) and touches map[i] only where a ray passed: 8*M is its
+    # algorithmic traffic (+ 8 bytes per updated voxel and the clears, a few percent) - not the 12*M round 1 quoted
+    for k, b in (("k_ray_sweep", 8.0 * M), ("k_mapbits", 4.0 * M + M / 8.0)):
         if k in kern and kern[k]["avg_us"] > 0:
             out.setdefault("roofline", {})[k] = {"alg_bytes": b, "GBps": b / (kern[k]["avg_us"] * 1e-6) / 1e9, "frac_of_8TBps": b / (kern[k]["avg_us"] * 1e-6) / 8e12}
     print(json.dumps(out), flush=True)
