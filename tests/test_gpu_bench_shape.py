@@ -376,3 +376,44 @@ def test_voxels_as_pc_debug_clouds(oracle, hip):
     assert len(bg) > 100 and (bg[:, 3] > dev.dp.voxel_map__thresholds__new_obstacles).all()
     # x outer, y, z inner: x never decreases
     assert (np.diff(bg[:, 0]) >= 0).all()
+
+
+@pytest.mark.parametrize("voxel_size", [0.25, 0.1])
+def test_single_pass_input_points_on_cell_boundaries(oracle, hip, voxel_size):
+    """k_key1 reads the input once and encodes the survivors in a reference lattice; points within a rounding band of a
+    cell boundary are re-encoded with the frame's own offset.  Frames full of points a few ulps around cell boundaries
+    (of the reference lattice and of the frame's own), with different bounding boxes per frame, against the oracle."""
+    sensor = "os1-16"
+    ref, dev = make_pair(oracle, hip, sensor, voxel_size, max_batch=6, ground_points_max_distance=6 * voxel_size)
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    h, w, _, _ = synth.SENSORS[sensor]
+    n = h * w
+    rng = np.random.default_rng(17)
+    scans, tfs = [], []
+    vs = np.float32(voxel_size)
+    for f in range(6):
+        # cell corners of a lattice shifted by a frame-specific whole number of cells, then nudged by -3..3 ulps / tiny offsets
+        base = np.float32([-15.0 + 3.1 * f, -20.0 + 1.7 * f, -1.0])
+        k = np.stack([rng.integers(0, int(30 / voxel_size), n), rng.integers(0, int(30 / voxel_size), n), rng.integers(0, int(6 / voxel_size), n)], axis=1)
+        p = (base + k.astype(np.float32) * vs).astype(np.float32)
+        nudge = rng.integers(-3, 4, (n, 3))
+        for _ in range(3):
+            up = np.nextafter(p, np.float32(1e9))
+            dn = np.nextafter(p, np.float32(-1e9))
+            p = np.where(nudge > 0, up, np.where(nudge < 0, dn, p))
+            nudge = nudge - np.sign(nudge)
+        tiny = rng.choice(np.float32([0, 0, 1e-6, -1e-6, 1e-5, -1e-5, 3e-4, -3e-4, 0.01]), (n, 3))
+        p = (p + tiny).astype(np.float32)
+        free = rng.random(n) < 0.2  # a fifth of the points anywhere
+        p[free] = rng.uniform([-18, -25, -1.2], [40, 30, 8], (int(free.sum()), 3)).astype(np.float32)
+        t = np.float32([[1, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 0.0]])  # world = sensor: the boundaries stay where they were put
+        scans.append(ScanData(x=np.ascontiguousarray(p[:, 0]), y=np.ascontiguousarray(p[:, 1]), z=np.ascontiguousarray(p[:, 2]), width=w, height=h, stride_bytes=4))
+        tfs.append(t)
+    tfs = np.stack(tfs)
+    da, pa, ga = ref.process_batch(scans, tfs, debug=True)
+    db, pb, gb = dev.process_batch(scans, tfs, debug=True)
+    np.testing.assert_array_equal(pb, pa)
+    for x, y in zip(ga, gb):
+        assert_scan_debug_equal(x, y)
+    assert min(len(x["weighted"]) for x in ga) > 2000

@@ -158,6 +158,185 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key2(const FrameArgs* args, co
       *out++ = code[j];
 }
 
+// ---- one pass over the input instead of two ------------------------------------------------------------------------
+// The lattice of a frame hangs on its own bounding box (voxel_grid_weighted.cpp:72-106: offset = floor(min * inv) * leaf -
+// align offset), so the cell of a point is only known once every point has been seen: k_bbox + k_key2 read the columns
+// twice.  All such lattices are translates of each other by whole cells - up to float rounding.  k_key1 therefore reads the
+// input ONCE: bounding box as k_bbox, and every survivor's cell in a *reference* lattice anchored at the operation area's
+// corner (the same expressions with the reference offset).  k_frame_lds shifts the reference cells by the integer
+// difference of the two offsets.  A point whose reference position lies within `eps` cells of a cell boundary could land
+// in another cell under the frame's own offset (the float subtraction / product round differently): such *fragile* points
+// (a fraction of a percent) are kept aside by their index in the cloud and encoded later with the exact
+// expression of the reference.  eps is a bound on all rounding differences (see fill_ref_lattice), far above them.
+struct RefLattice
+{
+  float off[3];     // reference offset: fl(fl(min_b_ref * leaf) - aco), as voxel_grid_weighted.cpp:80-100 would compute it
+  float eps;        // fragile band around cell boundaries, in cells
+  int32_t dims[3];  // reference cells per axis (<= 2048, 2048, 1024: packed 11 + 11 + 10 bits)
+  int32_t on;
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* args, const GridParams g, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
+{
+  uint32_t FRAME, BX, GX;
+  if (!frame_block(g, FRAME, BX, GX))
+    return;
+  (void)GX;
+  const FrameArgs& a = args[FRAME];
+  const uint32_t base_blk = BX * KEY2_THREADS * KEY2_PPT;
+  if (base_blk >= a.n)
+    return;
+  const uint32_t i0 = base_blk + threadIdx.x * KEY2_PPT;
+  float px[KEY2_PPT], py[KEY2_PPT], pz[KEY2_PPT];
+  if (PACKED && i0 + KEY2_PPT <= a.n)
+  {
+    const float4* cx = reinterpret_cast<const float4*>(a.x + static_cast<uint64_t>(i0) * 4);
+    const float4* cy = reinterpret_cast<const float4*>(a.y + static_cast<uint64_t>(i0) * 4);
+    const float4* cz = reinterpret_cast<const float4*>(a.z + static_cast<uint64_t>(i0) * 4);
+    const float4 x0 = cx[0], x1 = cx[1], y0 = cy[0], y1 = cy[1], z0 = cz[0], z1 = cz[1];
+    px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
+    py[0] = y0.x, py[1] = y0.y, py[2] = y0.z, py[3] = y0.w, py[4] = y1.x, py[5] = y1.y, py[6] = y1.z, py[7] = y1.w;
+    pz[0] = z0.x, pz[1] = z0.y, pz[2] = z0.z, pz[3] = z0.w, pz[4] = z1.x, pz[5] = z1.y, pz[6] = z1.z, pz[7] = z1.w;
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < KEY2_PPT; j++)
+    {
+      const uint32_t i = i0 + j;
+      const bool ok = i < a.n;
+      px[j] = ok ? ldf(a.x, a.stride, i) : 0.0f;
+      py[j] = ok ? ldf(a.y, a.stride, i) : 0.0f;
+      pz[j] = ok ? ldf(a.z, a.stride, i) : 0.0f;
+    }
+  }
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
+  uint32_t code[KEY2_PPT];
+  uint32_t cnt = 0, n_surv = 0, frag_mask = 0;
+  uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their indices in the cloud
+#pragma unroll
+  for (int j = 0; j < KEY2_PPT; j++)
+  {
+    code[j] = FR_CODE_NONE;
+    const float p0 = px[j], p1 = py[j], p2 = pz[j];
+    bool keep = i0 + j < a.n && isfinite(p0) && isfinite(p1) && isfinite(p2);
+    keep = keep && (p0 < g.ex_min[0] || p1 < g.ex_min[1] || p2 < g.ex_min[2] || p0 > g.ex_max[0] || p1 > g.ex_max[1] || p2 > g.ex_max[2]);
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
+      q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
+    keep = keep && !(q[0] < g.op_min[0] || q[1] < g.op_min[1] || q[2] < g.op_min[2] || q[0] > g.op_max[0] || q[1] > g.op_max[1] || q[2] > g.op_max[2]);
+    if (!keep)
+      continue;
+    n_surv++;
+    bool fragile = false;
+    uint32_t kk[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      const int o = f2ord(q[c]);  // pcl::getMinMax3D (voxel_grid_weighted.cpp:58)
+      mn[c] = min(mn[c], o);
+      mx[c] = max(mx[c], o);
+      const float t = __fmul_rn(__fsub_rn(q[c], rl.off[c]), g.inv[c]);
+      const float fl = floorf(t);
+      const float fr = __fsub_rn(t, fl);  // exact
+      fragile = fragile || !(fr >= rl.eps && fr <= 1.0f - rl.eps) || fl < 0.0f || fl >= static_cast<float>(rl.dims[c]);
+      kk[c] = static_cast<uint32_t>(static_cast<int>(fl));
+    }
+    if (fragile)
+      frag_mask |= 1u << j;  // kept aside by its index: k_frame_lds fetches the point again and encodes it exactly
+    else
+    {
+      code[j] = kk[0] | (kk[1] << 11) | (kk[2] << 22);
+      cnt++;
+    }
+  }
+  // bounding box and survivor count of the block (as k_bbox) ...
+  uint32_t ns = n_surv;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1)
+  {
+    ns += __shfl_xor(ns, s);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      mn[c] = min(mn[c], __shfl_xor(mn[c], s));
+      mx[c] = max(mx[c], __shfl_xor(mx[c], s));
+    }
+  }
+  __shared__ int s_red[KEY2_THREADS / 64][7];
+  __shared__ uint32_t s_wsum[KEY2_THREADS / 64], s_fsum[KEY2_THREADS / 64];
+  __shared__ uint32_t s_base, s_fbase;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(cnt);
+  const uint32_t fcnt = __popc(frag_mask), fincl = wave_incl_scan(fcnt);
+  if (lane == 63)
+  {
+    s_wsum[wave] = incl;
+    s_fsum[wave] = fincl;
+  }
+  if (lane == 0)
+  {
+    s_red[wave][0] = static_cast<int>(ns);
+    for (int c = 0; c < 3; c++)
+    {
+      s_red[wave][1 + c] = mn[c];
+      s_red[wave][4 + c] = mx[c];
+    }
+  }
+  __syncthreads();
+  uint32_t off = incl - cnt, total = 0, foff = fincl - fcnt, ftotal = 0;
+#pragma unroll
+  for (int w = 0; w < KEY2_THREADS / 64; w++)
+  {
+    const uint32_t x = s_wsum[w], y = s_fsum[w];
+    off += w < wave ? x : 0u;
+    total += x;
+    foff += w < wave ? y : 0u;
+    ftotal += y;
+  }
+  if (threadIdx.x == 0)
+  {
+    s_base = total ? atomicAdd(&sa.counts[2 * FRAME], total) : 0u;
+    s_fbase = ftotal ? atomicAdd(&sa.counts[2 * FRAME + 1], ftotal) : 0u;
+    uint32_t tot = 0;
+    for (int w = 0; w < KEY2_THREADS / 64; w++)
+    {
+      tot += static_cast<uint32_t>(s_red[w][0]);
+      for (int c = 0; c < 3; c++)
+      {
+        mn[c] = min(mn[c], s_red[w][1 + c]);
+        mx[c] = max(mx[c], s_red[w][4 + c]);
+      }
+    }
+    if (tot)
+    {
+      FrameHdr& h = hdrs[FRAME];
+      atomicAdd(&h.n_in, tot);
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        atomicMin(&h.bb_min[c], mn[c]);
+        atomicMax(&h.bb_max[c], mx[c]);
+      }
+    }
+  }
+  __syncthreads();
+  // ... and the reference cells of its (non-fragile) survivors, in point order
+  uint32_t* out = sa.keys + static_cast<size_t>(FRAME) * pt_cap + s_base + off;
+#pragma unroll
+  for (int j = 0; j < KEY2_PPT; j++)
+    if (code[j] != FR_CODE_NONE)
+      *out++ = code[j];
+  uint32_t* fout = frag + s_fbase + foff;
+#pragma unroll
+  for (int j = 0; j < KEY2_PPT; j++)
+    if ((frag_mask >> j) & 1u)
+      *fout++ = i0 + j;
+}
+
 // ---- helpers of k_frame_lds ----------------------------------------------------------------------------------------
 // node descriptor: brick coordinates (9 + 9 + 6 bits) and, from pass a of phase 4 on, the brick's 2x2x2 octant occupancy
 __device__ __forceinline__ uint32_t fr_pack(uint32_t bx, uint32_t by, uint32_t bz) { return bx | (by << 9) | (bz << 18); }
@@ -289,7 +468,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
                                                          VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
                                                          const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
                                                          const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,
-                                                         CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof)
+                                                         CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof, const RefLattice rl, const FrameArgs* __restrict__ args)
 {
   __shared__ __attribute__((aligned(16))) unsigned long long s_bb[FR_BB64];  // brick-lattice bitmap (bit = linear brick id) + exclusive popcount prefix per
                                                                             // 64-bit word; during the counting / rank phases: one byte counter per voxel
@@ -309,7 +488,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   uint16_t* s_par = reinterpret_cast<uint16_t*>(s_x2);
   const uint32_t FRAME = blockIdx.x;
   FrameHdr& h = hdrs[FRAME];
-  const uint32_t n_keys = sa.counts[2 * FRAME];
+  // single-pass input (k_key1): the list holds reference cells, the fragile points wait beside it with their coordinates
+  const uint32_t n_ref = sa.counts[2 * FRAME];
+  const uint32_t n_frag = rl.on ? sa.counts[2 * FRAME + 1] : 0u;
+  const uint32_t n_keys = n_ref + n_frag;
   if (h.n_in == 0 || n_keys == 0)
     return;  // k_init_hdr left V = C = 0
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
@@ -367,16 +549,96 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         c[u] = base + u < n_keys ? codes[base + u] : FR_CODE_NONE;
     }
   };
+  uint32_t* codes_w = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
+  // brick code of lattice cell (k0, k1, k2) of the frame's own lattice; a cell outside it (a rounding artefact) is aliased
+  // through the linear index as the reference does (voxel_grid_weighted.cpp:137) and dropped when it leaves the index range
+  auto cell_code = [&](int k0, int k1, int k2) -> uint32_t {
+    if (k0 < 0 || k0 >= h.div_b[0] || k1 < 0 || k1 >= h.div_b[1] || k2 < 0 || k2 >= h.div_b[2])
+    {
+      const uint32_t key = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
+      if (key >= h.n_cells)
+        return FR_CODE_NONE;
+      key_to_ijk(h, key, k0, k1, k2);
+    }
+    return (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
+  };
+  int shift[3] = {0, 0, 0};
+  if (rl.on)
+  {
+    // whole cells between the reference lattice and this frame's: both offsets are floats, their difference times inv lies
+    // within eps of an integer
+    for (int a = 0; a < 3; a++)
+      shift[a] = static_cast<int>(rint((static_cast<double>(h.offset[a]) - static_cast<double>(rl.off[a])) * static_cast<double>(g.inv[a])));
+    // the fragile points: exact expression with the frame's own offset (voxel_grid_weighted.cpp:131-136); their codes
+    // follow the reference cells in the list
+    const uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
+    const FrameArgs& fa = args[FRAME];
+    for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
+    {
+      const uint32_t pi = frag[i];
+      const float p0 = ldf(fa.x, fa.stride, pi), p1 = ldf(fa.y, fa.stride, pi), p2 = ldf(fa.z, fa.stride, pi);
+      float q[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)  // the very transform of k_key1
+        q[r] = __fadd_rn(__fmul_rn(fa.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(fa.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(fa.tf[4 * r + 2], p2), fa.tf[4 * r + 3])));
+      const int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], h.offset[0]), g.inv[0])));
+      const int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], h.offset[1]), g.inv[1])));
+      const int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], h.offset[2]), g.inv[2])));
+      const uint32_t cd = cell_code(k0, k1, k2);
+      codes_w[n_ref + i] = cd;
+      if (cd != FR_CODE_NONE)
+        atomicOr(&s_bits[cd >> 11], 1u << ((cd >> 6) & 31u));
+    }
+  }
   // ---- 1: the occupied bricks.  Consecutive codes of a thread mostly share their brick: one LDS atomic per run.
   {
     uint32_t c[KPT], cn[KPT];
+    const uint32_t n_pass1 = rl.on ? n_ref : n_keys;
+    auto load1 = [&](uint32_t base, uint32_t cc[KPT]) {
+      if (vec_ok && base + KPT <= n_pass1)
+      {
+#pragma unroll
+        for (int q = 0; q < KPT / 4; q++)
+        {
+          const uint4 a = *reinterpret_cast<const uint4*>(codes + base + 4 * q);
+          cc[4 * q] = a.x, cc[4 * q + 1] = a.y, cc[4 * q + 2] = a.z, cc[4 * q + 3] = a.w;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int u = 0; u < KPT; u++)
+          cc[u] = base + u < n_pass1 ? codes[base + u] : FR_CODE_NONE;
+      }
+    };
     uint32_t base = tid * KPT;
-    if (base < n_keys)
-      load_codes(base, c);
-    for (; base < n_keys; base += FR_THREADS * KPT)
+    if (base < n_pass1)
+      load1(base, c);
+    for (; base < n_pass1; base += FR_THREADS * KPT)
     {
-      if (base + FR_THREADS * KPT < n_keys)
-        load_codes(base + FR_THREADS * KPT, cn);  // the next round's codes are on their way while this round works
+      if (base + FR_THREADS * KPT < n_pass1)
+        load1(base + FR_THREADS * KPT, cn);  // the next round's codes are on their way while this round works
+      if (rl.on)
+      {
+        // reference cells -> brick codes of the frame's lattice, written back for the later passes
+#pragma unroll
+        for (int u = 0; u < KPT; u++)
+          if (base + u < n_pass1)
+            c[u] = cell_code(static_cast<int>(c[u] & 2047u) - shift[0], static_cast<int>((c[u] >> 11) & 2047u) - shift[1], static_cast<int>(c[u] >> 22) - shift[2]);
+        if (vec_ok && base + KPT <= n_pass1)
+        {
+#pragma unroll
+          for (int q = 0; q < KPT / 4; q++)
+            *reinterpret_cast<uint4*>(codes_w + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        }
+        else
+        {
+#pragma unroll
+          for (int u = 0; u < KPT; u++)
+            if (base + u < n_pass1)
+              codes_w[base + u] = c[u];
+        }
+      }
       uint32_t cur = FR_CODE_NONE;
 #pragma unroll
       for (int u = 0; u < KPT; u++)
@@ -448,7 +710,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   FR_STAMP(2);
   // ---- 3a: occupancy words.  A thread ORs the run of its consecutive codes that share a brick with one LDS atomic per
   // 32-bit half, and rewrites its codes as node * 64 + bit: the later passes need no bitmap lookup.
-  uint32_t* codes_w = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
   {
     uint32_t c[KPT], cn[KPT];
     uint32_t base = tid * KPT;

@@ -237,6 +237,7 @@ struct Workspace
   uint32_t* d_ptrank = nullptr;
   SlabArrays sa{};  // key list / extras of the LDS-slab voxelisation (keys share d_ptrank's storage)
   FrameScratch fs{};  // row tables of the brick-first frame kernel (kernels_frame.h)
+  RefLattice ref_lattice{};  // single-pass input: the reference lattice the list's cells refer to (on = 0: brick codes from k_key2)
   bool frame_fused = false;  // k_key2 ran: launch_cluster runs k_frame_lds (voxel records + clustering in one kernel)
   float* d_stage = nullptr;  // F * pt_cap * 5 words: x, y, z, intensity, range of host-resident inputs
   PackedFrame* d_packed = nullptr;
@@ -913,6 +914,35 @@ inline dim3 fgrid(const GridParams& g, uint32_t gx)
   return dim3(8u * ((g.n_frames + 7u) / 8u) * gx);
 }
 
+// Reference lattice of the single-pass input (kernels_frame.h, k_key1): what voxel_grid_weighted.cpp:72-106 yields for a cloud
+// whose minimum is the operation area's corner, and the band around cell boundaries inside which the frame's own offset may
+// round a point into the neighbouring cell.  Bound: |q - O| <= 2c (c = largest |coordinate|), the subtraction and the product
+// each round by 2^-24 relative -> 2 * 2c * inv * 2^-23 cells per offset; the two offsets differ from whole cells by their own
+// roundings (2 * c * 2^-23 * inv) and by leaf * inv != 1 (<= 2^-22 per cell of distance).  eps is four times the sum.
+RefLattice fill_ref_lattice(const GridParams& g)
+{
+  RefLattice rl{};
+  static const bool on = !(std::getenv("VOFOD_ONEPASS") && std::atoi(std::getenv("VOFOD_ONEPASS")) == 0);
+  float cmax = 0.0f, dmax = 0.0f, inv_max = 0.0f;
+  for (int a = 0; a < 3; a++)
+  {
+    const int min_b = static_cast<int>(std::floor(g.op_min[a] * g.inv[a]));
+    float offset = static_cast<float>(min_b) * g.leaf[a];
+    if (g.align)
+      offset = offset - g.aco[a];
+    rl.off[a] = offset;
+    rl.dims[a] = static_cast<int>(std::floor((g.op_max[a] - offset) * g.inv[a])) + 2;
+    cmax = std::max(cmax, std::max(std::fabs(g.op_min[a]), std::fabs(g.op_max[a])) + g.leaf[a]);
+    dmax = std::max(dmax, static_cast<float>(rl.dims[a]));
+    inv_max = std::max(inv_max, g.inv[a]);
+  }
+  const float u = 1.1920929e-7f;  // 2^-23
+  const float e1 = 2.0f * (2.0f * cmax) * inv_max * u, e2 = 2.0f * cmax * u * inv_max + dmax * 2.0f * u;
+  rl.eps = 4.0f * (e1 + e2) + 1e-4f;
+  rl.on = on && rl.eps < 0.2f && rl.dims[0] > 0 && rl.dims[1] > 0 && rl.dims[2] > 0 && rl.dims[0] <= 2048 && rl.dims[1] <= 2048 && rl.dims[2] <= 1024;
+  return rl;
+}
+
 // kernel chain K1-K6 over frames [0,n): bbox -> lattice -> occupancy bitmap -> ranks -> weighted cloud
 int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, uint32_t max_pts, bool want_ptrank, bool two_phase, const BrickParams* bricks = nullptr,
                     bool lean_hint = false)
@@ -934,29 +964,46 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs);
   const uint32_t gb = std::max(1u, std::min((max_pts + 2047u) / 2048u, 1024u));  // 8 points per thread: few header atomics
-  KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
+  static const bool frame_on = !(std::getenv("VOFOD_FRAME_LDS") && std::atoi(std::getenv("VOFOD_FRAME_LDS")) == 0);
+  const bool frame_plan = frame_on && ws.lean_emit && n >= 4 && !want_ptrank && !two_phase;
+  ws.ref_lattice = RefLattice{};
+  if (frame_plan)
+    ws.ref_lattice = fill_ref_lattice(g);
+  bool packed = frame_plan;
+  for (uint32_t f = 0; f < n && packed; f++)
+  {
+    const FrameArgs& a = ws.h_args[f];
+    packed = a.stride == 4 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
+  }
+  if (frame_plan && ws.ref_lattice.on)
+  {
+    // one pass over the input: bounding box + reference cells (k_key1), then the frames' lattices
+    HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
+    if (packed)
+      KLAUNCH(h, k_key1<true>, fgrid(g, gb), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
+    else
+      KLAUNCH(h, k_key1<false>, fgrid(g, gb), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
+  }
+  else
+    KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
   KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
   // Batches whose clustering will run inside LDS (plan_lds_ccl): brick-first frame kernel (kernels_frame.h).  One pass over
   // the input writes the survivors' brick codes; k_frame_lds (launched by launch_cluster) builds the voxel records and
   // clusters them on the same LDS image.  VOFOD_FRAME_LDS=0 keeps the slab voxeliser + k_brick_ccl_lds of round 1.
-  static const bool frame_on = !(std::getenv("VOFOD_FRAME_LDS") && std::atoi(std::getenv("VOFOD_FRAME_LDS")) == 0);
   ws.frame_fused = false;
-  if (frame_on && ws.lean_emit && n >= 4 && !want_ptrank)
+  if (frame_plan)
   {
-    HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
-    bool packed = true;
-    for (uint32_t f = 0; f < n; f++)
+    if (!ws.ref_lattice.on)
     {
-      const FrameArgs& a = ws.h_args[f];
-      packed = packed && a.stride == 4 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
+      HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
+      const uint32_t gk = std::max(1u, (max_pts + KEY2_THREADS * KEY2_PPT - 1) / (KEY2_THREADS * KEY2_PPT));
+      if (packed)
+        KLAUNCH(h, k_key2<true>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
+      else
+        KLAUNCH(h, k_key2<false>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
     }
-    const uint32_t gk = std::max(1u, (max_pts + KEY2_THREADS * KEY2_PPT - 1) / (KEY2_THREADS * KEY2_PPT));
-    if (packed)
-      KLAUNCH(h, k_key2<true>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
-    else
-      KLAUNCH(h, k_key2<false>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
     if (!h->ev_stagger)
       HIPCHK(hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->ev_stagger, h->stream));  // the next batch's chain may start its streaming kernels now
@@ -1197,7 +1244,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       {
         ws.frame_fused = false;
         KLAUNCH(h, k_frame_lds, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose,
-                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof);
+                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args);
         ws.finalize_fused = up_tables && mapclose;
         if (d_prof)
         {
