@@ -48,7 +48,7 @@ def run(name, sensor, vs, apriori, n_warm, n_timed):
     det = VoFOD(lib, sp, dp)
     scene = synth.make_scene(0, n_targets=3)
     if apriori:
-        det.load_apriori(synth.apriori_points(scene, vs, n_voxels=1_000_000))
+        det.load_apriori(synth.apriori_points(scene, vs, n_voxels=1_000_000, solid_ground_to=-1.2))
     else:
         # range-finder stand-in without a host round trip of the whole map: apriori-style ground disc, then reset latches by hand
         gx, gy = np.meshgrid(np.arange(-20, 30, vs), np.arange(-20, 30, vs), indexing="ij")

@@ -40,7 +40,7 @@ def main():
         sensor = rng.choice(["os1-16", "os1-16", "os1-128"])
         voxel = float(rng.choice([0.25, 0.25, 0.5]))  # sizes that tile the operation area (others make the reference throw: MAP_RANGE)
         tol = float(rng.choice([1.0, 1.5, 1.5, 2.0]))
-        n_batch = int(rng.choice([4, 6, 17, 130])) if sensor == "os1-16" else int(rng.choice([4, 6]))
+        n_batch = int(rng.choice([4, 6, 17, 130])) if sensor == "os1-16" else int(rng.choice([4, 6, 6, 130, 256]))
         n_warm = int(rng.integers(0, 5))
         use_apriori = bool(rng.integers(0, 2))
         desc = f"seed {seed}: {sensor} voxel {voxel} tol {tol} batch {n_batch} warm {n_warm} apriori {use_apriori}"
