@@ -552,13 +552,20 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   uint32_t* codes_w = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
   // brick code of lattice cell (k0, k1, k2) of the frame's own lattice; a cell outside it (a rounding artefact) is aliased
   // through the linear index as the reference does (voxel_grid_weighted.cpp:137) and dropped when it leaves the index range
+  const int dv0 = h.div_b[0], dv1 = h.div_b[1], dv2 = h.div_b[2];  // (the header lives in global memory: keep the lattice in registers)
+  const uint32_t n_cells = h.n_cells;
+  const float hoff0 = h.offset[0], hoff1 = h.offset[1], hoff2 = h.offset[2];
   auto cell_code = [&](int k0, int k1, int k2) -> uint32_t {
-    if (k0 < 0 || k0 >= h.div_b[0] || k1 < 0 || k1 >= h.div_b[1] || k2 < 0 || k2 >= h.div_b[2])
+    // one unsigned compare per axis: negative values wrap above every lattice size
+    if (static_cast<uint32_t>(k0) >= static_cast<uint32_t>(dv0) || static_cast<uint32_t>(k1) >= static_cast<uint32_t>(dv1) || static_cast<uint32_t>(k2) >= static_cast<uint32_t>(dv2))
     {
       const uint32_t key = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
-      if (key >= h.n_cells)
+      if (key >= n_cells)
         return FR_CODE_NONE;
-      key_to_ijk(h, key, k0, k1, k2);
+      k2 = static_cast<int>(key / static_cast<uint32_t>(dxy));
+      const uint32_t rem = key - static_cast<uint32_t>(k2) * dxy;
+      k1 = static_cast<int>(rem / static_cast<uint32_t>(dx));
+      k0 = static_cast<int>(rem - static_cast<uint32_t>(k1) * dx);
     }
     return (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
   };
@@ -581,9 +588,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
 #pragma unroll
       for (int r = 0; r < 3; r++)  // the very transform of k_key1
         q[r] = __fadd_rn(__fmul_rn(fa.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(fa.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(fa.tf[4 * r + 2], p2), fa.tf[4 * r + 3])));
-      const int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], h.offset[0]), g.inv[0])));
-      const int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], h.offset[1]), g.inv[1])));
-      const int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], h.offset[2]), g.inv[2])));
+      const int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], hoff0), g.inv[0])));
+      const int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], hoff1), g.inv[1])));
+      const int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], hoff2), g.inv[2])));
       const uint32_t cd = cell_code(k0, k1, k2);
       codes_w[n_ref + i] = cd;
       if (cd != FR_CODE_NONE)
@@ -1060,9 +1067,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const uint32_t rank = Qz + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
       const int k0 = 4 * bx + xx, k1 = 4 * by + yy, k2 = 4 * bz + zz;
       float4 pt;
-      pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), h.offset[0]);
-      pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), h.offset[1]);
-      pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), h.offset[2]);
+      pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), hoff0);
+      pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), hoff1);
+      pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), hoff2);
       pt.w = __uint_as_float(static_cast<uint32_t>(*cntp++));  // points in the voxel (the record list below adds what a byte cannot hold)
       va.pts[rank] = pt;
       va.bb[rank] = i;
@@ -1663,9 +1670,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
             continue;
           const int p = __ffsll(static_cast<long long>(a)) - 1;
           a &= a - 1;
-          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), h.offset[0]);
-          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), h.offset[1]);
-          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), h.offset[2]);
+          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), hoff0);
+          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), hoff1);
+          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), hoff2);
           const int mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
           const int my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
           const int mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
