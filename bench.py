@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="a step lasts ~1.2 ms: 200 steps keep the timed region long enough to be stable")
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400, help="a step lasts ~0.6 ms: 400 steps keep the timed region long enough to be stable")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps (the clocks ramp up during the first ones)")
     ap.add_argument("--frames", type=int, default=256, help="independent scans per GPU per step (one workgroup per frame clusters in LDS: 256 frames fill the 256 CUs)")
     ap.add_argument("--voxel-size", type=float, default=0.25)
     ap.add_argument("--sensor", default="os1-128")
