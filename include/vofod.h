@@ -207,8 +207,9 @@ enum {
   VOFOD_SCAN_DEFAULT = 0,
   VOFOD_SCAN_NO_MAP_UPDATE = 1,  /* read-only map: skip updateVMaps/++its and keep exploreToGround's
                                     frontier writes in a per-scan overlay (batched mode) */
-  VOFOD_SCAN_AUTO_RAYCAST = 2    /* emulate the detached raycast thread :951-957 deterministically:
-                                    after ++its finish the pending raycast, then begin one for this scan */
+  VOFOD_SCAN_AUTO_RAYCAST = 2    /* emulate the detached raycast thread :951-957 deterministically: after ++its EITHER
+                                    finish the pending raycast OR (none pending) begin one for this scan - as in the
+                                    reference, where a new thread starts only when none runs, a pass covers every other scan */
 };
 
 /* --------------------------------------------------------------- lifecycle */
