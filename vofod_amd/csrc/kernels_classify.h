@@ -20,7 +20,9 @@ using namespace vk;
 
 constexpr int EX_MAX_R = 32;                                        // Manhattan radius handled on the device
 constexpr int EX_SIDE = 2 * EX_MAX_R + 1;                            // 65
-constexpr uint32_t EX_CELLS = EX_SIDE * EX_SIDE * EX_SIDE;           // 274 625 visited bits (34 KB of LDS)
+constexpr uint32_t EX_CELLS = EX_SIDE * EX_SIDE * EX_SIDE;           // 274 625 visited bits: 34 KB per frame in global memory (L2), all-zero
+                                                                     // outside a fill.  Not in LDS: a fill's wave then fits a CU beside a frame
+                                                                     // workgroup (153 KB of LDS) and the tail never keeps a CU from the next batch
 constexpr uint32_t EX_WORDS = (EX_CELLS + 31) / 32;
 constexpr uint32_t EX_MAX_JOBS = 1024;                               // explore jobs per frame handled on the device
 
@@ -55,9 +57,8 @@ __device__ __forceinline__ uint32_t pack_rel(int dx, int dy, int dz) { return st
 __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin, const uint32_t* __restrict__ job_end,
                                                 const int* __restrict__ members, float* __restrict__ map, unsigned long long* __restrict__ overlay_all,
                                                 uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all,
-                                                uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results)
+                                                uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all)
 {
-  __shared__ uint32_t visited[EX_WORDS];
   __shared__ uint8_t s_float[EX_MAX_JOBS];
   __shared__ uint8_t s_walk[6 * 32];
   const int lane = threadIdx.x;
@@ -71,9 +72,7 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
   uint32_t* explored = explored_all + static_cast<uint64_t>(slot) * ep.stack_cap;
   uint32_t* ovl_list = ovl_list_all + static_cast<uint64_t>(slot) * ep.stack_cap;
   uint32_t* touched = touched_all + static_cast<uint64_t>(slot) * ep.stack_cap;
-  for (uint32_t w = lane; w < EX_WORDS; w += 64)
-    visited[w] = 0;
-  __syncthreads();
+  uint32_t* visited = visited_all + static_cast<uint64_t>(slot) * EX_WORDS;  // clean on entry: every fill resets what it set
 
   auto map_read = [&](uint64_t li) -> float {
     // the overlay is updated with atomics (L2); read it there too so this CU's L1 cannot serve a stale word
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
       {
         stack[0] = pack_rel(0, 0, 0);
         const uint32_t c = (EX_MAX_R * EX_SIDE + EX_MAX_R) * EX_SIDE + EX_MAX_R;
-        visited[c >> 5] = 1u << (c & 31);
+        atomicOr(&visited[c >> 5], 1u << (c & 31));
         touched[0] = c;
       }
       __syncthreads();
@@ -221,22 +220,24 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
         if (unknown)
         {
           const int nb[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}};
+          // the six test-and-set operations go out together (global memory: one round trip for all of them)
+          uint32_t oldw[6], bitq[6];
+          bool okq[6];
 #pragma unroll
           for (int q = 0; q < 6; q++)
           {
             const int tx = dx + nb[q][0], ty = dy + nb[q][1], tz = dz + nb[q][2];
             const int ax = ox + tx, ay = oy + ty, az = oz + tz;
-            if (ax < 0 || ax > mg.sx - 1 || ay < 0 || ay > mg.sy - 1 || az < 0 || az > mg.sz - 1)
-              continue;
             const int tmd = abs(tx) + abs(ty) + abs(tz);
-            if (!(static_cast<float>(tmd) <= max_voxel_dist))
-              continue;
-            const uint32_t c = ((tz + EX_MAX_R) * EX_SIDE + (ty + EX_MAX_R)) * EX_SIDE + (tx + EX_MAX_R);
-            const uint32_t bit = 1u << (c & 31);
-            if (atomicOr(&visited[c >> 5], bit) & bit)
-              continue;
-            mine[n_mine++] = pack_rel(tx, ty, tz);
+            okq[q] = !(ax < 0 || ax > mg.sx - 1 || ay < 0 || ay > mg.sy - 1 || az < 0 || az > mg.sz - 1) && static_cast<float>(tmd) <= max_voxel_dist;
+            const uint32_t c = okq[q] ? ((tz + EX_MAX_R) * EX_SIDE + (ty + EX_MAX_R)) * EX_SIDE + (tx + EX_MAX_R) : 0u;
+            bitq[q] = 1u << (c & 31);
+            oldw[q] = okq[q] ? atomicOr(&visited[c >> 5], bitq[q]) : 0xffffffffu;
           }
+#pragma unroll
+          for (int q = 0; q < 6; q++)
+            if (okq[q] && !(oldw[q] & bitq[q]))
+              mine[n_mine++] = pack_rel(dx + nb[q][0], dy + nb[q][1], dz + nb[q][2]);
         }
         // wave-wide exclusive scan of the push counts
         uint32_t incl = static_cast<uint32_t>(n_mine);
@@ -271,11 +272,12 @@ __global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const Ma
       if (n_touched <= ep.stack_cap)
       {
         for (uint32_t e = lane; e < n_touched; e += 64)
-          visited[touched[e] >> 5] = 0;
+          __hip_atomic_store(&visited[touched[e] >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       else
         for (uint32_t w = lane; w < EX_WORDS; w += 64)
-          visited[w] = 0;
+          __hip_atomic_store(&visited[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
       __syncthreads();
       if (connected)
       {

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* args, co
     const float p0 = px[j], p1 = py[j], p2 = pz[j];
     bool keep = i0 + j < a.n && isfinite(p0) && isfinite(p1) && isfinite(p2);
     keep = keep && (p0 < g.ex_min[0] || p1 < g.ex_min[1] || p2 < g.ex_min[2] || p0 > g.ex_max[0] || p1 > g.ex_max[1] || p2 > g.ex_max[2]);
+    if (!__any(keep))
+      continue;  // a wave of no-return pixels ((0,0,0): inside the exclude box) - whole rings of them look at the sky
     float q[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded

@@ -403,6 +403,7 @@ struct ExploreBufs
   size_t jobs_cap = 0, members_cap = 0;
   unsigned long long* d_overlay = nullptr;
   uint32_t *d_stack = nullptr, *d_explored = nullptr, *d_touched = nullptr, *d_ovl_list = nullptr, *d_ovl_count = nullptr, *d_job_begin = nullptr;
+  uint32_t* d_visited = nullptr;  // per frame slot: visited bits of the running flood fill (all-zero between fills)
   vc::ExploreJob* d_jobs = nullptr;
   vc::ExploreResult* d_results = nullptr;
   int* d_members = nullptr;
@@ -1391,7 +1392,7 @@ int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
   if (eb.F < F)
   {
     for (void* p : {static_cast<void*>(eb.d_overlay), static_cast<void*>(eb.d_stack), static_cast<void*>(eb.d_explored), static_cast<void*>(eb.d_touched),
-                    static_cast<void*>(eb.d_ovl_list), static_cast<void*>(eb.d_ovl_count), static_cast<void*>(eb.d_job_begin)})
+                    static_cast<void*>(eb.d_ovl_list), static_cast<void*>(eb.d_ovl_count), static_cast<void*>(eb.d_job_begin), static_cast<void*>(eb.d_visited)})
       if (p)
         (void)hipFree(p);
     eb.F = F;
@@ -1404,6 +1405,8 @@ int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_ovl_count), sizeof(uint32_t) * F));
     HIPCHK(hipMemset(eb.d_ovl_count, 0, sizeof(uint32_t) * F));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_job_begin), sizeof(uint32_t) * (F + 1)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eb.d_visited), sizeof(uint32_t) * vc::EX_WORDS * F));
+    HIPCHK(hipMemset(eb.d_visited, 0, sizeof(uint32_t) * vc::EX_WORDS * F));
     HIPCHK(hipDeviceSynchronize());  // null-stream memsets vs non-blocking streams
   }
   if (eb.jobs_cap < n_jobs)
@@ -1798,7 +1801,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     KLAUNCH(h, vtd::k_tail_prep, dim3(n), dim3(vtd::TP_THREADS), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, ws.d_tailc,
             ws.d_dets);
     KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched, eb.d_ovl_list,
-            eb.d_ovl_count, eb.d_results);
+            eb.d_ovl_count, eb.d_results, eb.d_visited);
     KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets);
     HIPCHK(hipEventRecord(h->ev_explore, h->stream));
     if (phase == FRAMES_LAUNCH)
@@ -2178,7 +2181,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ep.no_update = no_update;
     ep.stack_cap = vc::EX_CELLS;
     KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, eb.d_job_begin, eb.d_job_begin + 1, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
-            eb.d_ovl_list, eb.d_ovl_count, eb.d_results);
+            eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited);
     HIPCHK(hipMemcpyAsync(results.data(), eb.d_results, sizeof(vc::ExploreResult) * jobs.size(), hipMemcpyDeviceToHost, h->stream));
     if (h->ev_explore)
       HIPCHK(hipEventRecord(h->ev_explore, h->stream));
