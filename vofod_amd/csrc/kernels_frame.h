@@ -53,6 +53,15 @@ struct FrameScratch
                              //   bit 63 of [3]: the row began inside the node's 64-node chunk (no carry to add)
 };
 
+// 16-byte load through the global address space (the column pointers come out of a struct in memory: the compiler would
+// otherwise emit flat loads, which also probe the LDS aperture)
+__device__ __forceinline__ float4 ldg_f4(const char* p)
+{
+  typedef float gf4 __attribute__((ext_vector_type(4)));
+  const gf4 v = *reinterpret_cast<const __attribute__((address_space(1))) gf4*>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ---- K1-K5a in one pass: brick codes of the surviving points ---------------------------------------------------
 constexpr int KEY2_THREADS = 256;
 constexpr int KEY2_PPT = 8;  // consecutive points per thread
@@ -177,13 +186,13 @@ struct RefLattice
 };
 
 template <bool PACKED>
-__global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* args, const GridParams g, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
+__global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
   (void)GX;
-  const FrameArgs& a = args[FRAME];
+  const FrameArgs a = args[FRAME];  // (a copy: the transform stays in scalar registers)
   const uint32_t base_blk = BX * KEY2_THREADS * KEY2_PPT;
   if (base_blk >= a.n)
     return;
@@ -191,10 +200,8 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* args, co
   float px[KEY2_PPT], py[KEY2_PPT], pz[KEY2_PPT];
   if (PACKED && i0 + KEY2_PPT <= a.n)
   {
-    const float4* cx = reinterpret_cast<const float4*>(a.x + static_cast<uint64_t>(i0) * 4);
-    const float4* cy = reinterpret_cast<const float4*>(a.y + static_cast<uint64_t>(i0) * 4);
-    const float4* cz = reinterpret_cast<const float4*>(a.z + static_cast<uint64_t>(i0) * 4);
-    const float4 x0 = cx[0], x1 = cx[1], y0 = cy[0], y1 = cy[1], z0 = cz[0], z1 = cz[1];
+    const char *cx = a.x + static_cast<uint64_t>(i0) * 4, *cy = a.y + static_cast<uint64_t>(i0) * 4, *cz = a.z + static_cast<uint64_t>(i0) * 4;
+    const float4 x0 = ldg_f4(cx), x1 = ldg_f4(cx + 16), y0 = ldg_f4(cy), y1 = ldg_f4(cy + 16), z0 = ldg_f4(cz), z1 = ldg_f4(cz + 16);
     px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
     py[0] = y0.x, py[1] = y0.y, py[2] = y0.z, py[3] = y0.w, py[4] = y1.x, py[5] = y1.y, py[6] = y1.z, py[7] = y1.w;
     pz[0] = z0.x, pz[1] = z0.y, pz[2] = z0.z, pz[3] = z0.w, pz[4] = z1.x, pz[5] = z1.y, pz[6] = z1.z, pz[7] = z1.w;
@@ -216,57 +223,50 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* args, co
   uint32_t code[KEY2_PPT];
   uint32_t cnt = 0, n_surv = 0, frag_mask = 0;
   uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their indices in the cloud
+  // Branch-free per point (the kernel was bound by the scalar unit's exec-mask bookkeeping, not by its float work): a value
+  // lies inside a closed interval iff the median of (value, low, high) is the value itself - one v_med3 + one compare per
+  // axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed point, which fails the
+  // operation-area test: the explicit isfinite() of the first crop is implied.
+  auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
+  const float eps_hi = 1.0f - rl.eps;
+  const float dmax[3] = {static_cast<float>(rl.dims[0] - 1), static_cast<float>(rl.dims[1] - 1), static_cast<float>(rl.dims[2] - 1)};
 #pragma unroll
   for (int j = 0; j < KEY2_PPT; j++)
   {
-    code[j] = FR_CODE_NONE;
     const float p0 = px[j], p1 = py[j], p2 = pz[j];
-    bool keep = i0 + j < a.n && isfinite(p0) && isfinite(p1) && isfinite(p2);
-    keep = keep && (p0 < g.ex_min[0] || p1 < g.ex_min[1] || p2 < g.ex_min[2] || p0 > g.ex_max[0] || p1 > g.ex_max[1] || p2 > g.ex_max[2]);
-    if (!__any(keep))
-      continue;  // a wave of no-return pixels ((0,0,0): inside the exclude box) - whole rings of them look at the sky
+    const bool in_ex = inside(p0, g.ex_min[0], g.ex_max[0]) & inside(p1, g.ex_min[1], g.ex_max[1]) & inside(p2, g.ex_min[2], g.ex_max[2]);
     float q[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
       q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
-    keep = keep && !(q[0] < g.op_min[0] || q[1] < g.op_min[1] || q[2] < g.op_min[2] || q[0] > g.op_max[0] || q[1] > g.op_max[1] || q[2] > g.op_max[2]);
-    if (!keep)
-      continue;
-    n_surv++;
-    bool fragile = false;
+    const bool in_op = inside(q[0], g.op_min[0], g.op_max[0]) & inside(q[1], g.op_min[1], g.op_max[1]) & inside(q[2], g.op_min[2], g.op_max[2]);
+    const bool keep = (i0 + j < a.n) & !in_ex & in_op;
+    bool solid = keep;  // survivor whose reference cell is certain
     uint32_t kk[3];
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
       const int o = f2ord(q[c]);  // pcl::getMinMax3D (voxel_grid_weighted.cpp:58)
-      mn[c] = min(mn[c], o);
-      mx[c] = max(mx[c], o);
+      mn[c] = min(mn[c], keep ? o : 0x7fffffff);
+      mx[c] = max(mx[c], keep ? o : static_cast<int>(0x80000000u));
       const float t = __fmul_rn(__fsub_rn(q[c], rl.off[c]), g.inv[c]);
       const float fl = floorf(t);
       const float fr = __fsub_rn(t, fl);  // exact
-      fragile = fragile || !(fr >= rl.eps && fr <= 1.0f - rl.eps) || fl < 0.0f || fl >= static_cast<float>(rl.dims[c]);
+      solid = solid & inside(fr, rl.eps, eps_hi) & inside(fl, 0.0f, dmax[c]);
       kk[c] = static_cast<uint32_t>(static_cast<int>(fl));
     }
-    if (fragile)
-      frag_mask |= 1u << j;  // kept aside by its index: k_frame_lds fetches the point again and encodes it exactly
-    else
-    {
-      code[j] = kk[0] | (kk[1] << 11) | (kk[2] << 22);
-      cnt++;
-    }
+    n_surv += keep ? 1u : 0u;
+    cnt += solid ? 1u : 0u;
+    code[j] = solid ? (kk[0] | (kk[1] << 11) | (kk[2] << 22)) : FR_CODE_NONE;
+    frag_mask |= (keep & !solid) ? (1u << j) : 0u;  // kept aside by its index: k_frame_lds fetches the point again and encodes it exactly
   }
   // bounding box and survivor count of the block (as k_bbox) ...
-  uint32_t ns = n_surv;
+  const uint32_t ns = wave_sum(n_surv);
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1)
+  for (int c = 0; c < 3; c++)
   {
-    ns += __shfl_xor(ns, s);
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-    {
-      mn[c] = min(mn[c], __shfl_xor(mn[c], s));
-      mx[c] = max(mx[c], __shfl_xor(mx[c], s));
-    }
+    mn[c] = wave_min(mn[c]);
+    mx[c] = wave_max(mx[c]);
   }
   __shared__ int s_red[KEY2_THREADS / 64][7];
   __shared__ uint32_t s_wsum[KEY2_THREADS / 64], s_fsum[KEY2_THREADS / 64];
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           uint32_t base = 0;
           if (lane == leader)
             base = atomicAdd(&s_no, static_cast<uint32_t>(__popcll(m)));
-          base = __shfl(base, leader);
+          base = __builtin_amdgcn_readlane(base, leader);
           if (kind[u] == 2u)
             opens[base + __popcll(m & ((1ull << lane) - 1ull))] = hv[u];
         }
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         uint32_t base = 0;
         if (lane == leader)
           base = atomicAdd(&s_nn, static_cast<uint32_t>(__popcll(m)));
-        base = __shfl(base, leader);
+        base = __builtin_amdgcn_readlane(base, leader);
         if (out)
           small[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
       }
@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         uint32_t base = 0;
         if (lane == leader)
           base = atomicAdd(&s_nh, static_cast<uint32_t>(__popcll(m)));
-        base = __shfl(base, leader);
+        base = __builtin_amdgcn_readlane(base, leader);
         if (keep)
           hits[base + __popcll(m & ((1ull << lane) - 1ull))] = hv;  // the hit list is dead: it holds the survivors
       }
@@ -1603,7 +1603,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     uint32_t base = 0;
     if (lane == leader)
       base = atomicAdd(&s_nh, static_cast<uint32_t>(__popcll(m)));
-    base = __shfl(base, leader);
+    base = __builtin_amdgcn_readlane(base, leader);
     if (is_root)
     {
       const uint32_t c = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
     {
-      const uint32_t lead = __shfl(c, __ffsll(static_cast<long long>(__ballot(1))) - 1);
+      const uint32_t lead = __builtin_amdgcn_readlane(c, __ffsll(static_cast<long long>(__ballot(1))) - 1);
       const bool same = c == lead && c < LB_ST_ROWS;
       const unsigned long long m_same = __ballot(same);
       if (__popcll(m_same) >= 8)
@@ -1705,16 +1705,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           rlo[a] = same ? lo[a] : 0x7fffffff;
           rhi[a] = same ? hi[a] : static_cast<int>(0x80000000u);
         }
+        rc = wave_sum(rc);
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1)
+        for (int a = 0; a < 3; a++)
         {
-          rc += __shfl_xor(rc, sft);
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-          {
-            rlo[a] = min(rlo[a], __shfl_xor(rlo[a], sft));
-            rhi[a] = max(rhi[a], __shfl_xor(rhi[a], sft));
-          }
+          rlo[a] = wave_min(rlo[a]);
+          rhi[a] = wave_max(rhi[a]);
         }
         const bool any_hit = __ballot(same && hit) != 0ull;
         if (lane == __ffsll(static_cast<long long>(m_same)) - 1)
@@ -1860,7 +1856,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           uint32_t base = 0;
           if (lane == leader)
             base = atomicAdd(&h.n_cand, static_cast<uint32_t>(__popcll(m)));
-          base = __shfl(base, leader);
+          base = __builtin_amdgcn_readlane(base, leader);
           if (cand)
           {
             CandMember cm;

@@ -26,6 +26,56 @@ __device__ __forceinline__ int f2ord(float f)
 }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
+// Data-parallel-primitive moves of the gfx9 VALU (no LDS crossbar involved): lanes without a valid source read 0.
+//   0x110 + s: row_shr:s (shift right by s lanes inside each row of 16), 0x142: row_bcast:15 (lane 15 of every row to the
+//   next row), 0x143: row_bcast:31 (lane 31 to the upper half); row_mask selects the rows that take the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v)
+{
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (every lane must be active)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+  v += dpp_mov0<0x111, 0xf>(v);
+  v += dpp_mov0<0x112, 0xf>(v);
+  v += dpp_mov0<0x114, 0xf>(v);
+  v += dpp_mov0<0x118, 0xf>(v);
+  v += dpp_mov0<0x142, 0xa>(v);
+  v += dpp_mov0<0x143, 0xc>(v);
+  return v;
+}
+
+// Wave-wide reductions as DPP moves (no LDS crossbar).  A lane without a valid source keeps its own value, which is the
+// identity of min / max; sums use the scan above.  The result is valid in every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov_self(int v)
+{
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_min(int v)
+{
+  v = min(v, dpp_mov_self<0x111, 0xf>(v));
+  v = min(v, dpp_mov_self<0x112, 0xf>(v));
+  v = min(v, dpp_mov_self<0x114, 0xf>(v));
+  v = min(v, dpp_mov_self<0x118, 0xf>(v));
+  v = min(v, dpp_mov_self<0x142, 0xa>(v));
+  v = min(v, dpp_mov_self<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+  v = max(v, dpp_mov_self<0x111, 0xf>(v));
+  v = max(v, dpp_mov_self<0x112, 0xf>(v));
+  v = max(v, dpp_mov_self<0x114, 0xf>(v));
+  v = max(v, dpp_mov_self<0x118, 0xf>(v));
+  v = max(v, dpp_mov_self<0x142, 0xa>(v));
+  v = max(v, dpp_mov_self<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+
 // Frame/block decode of the 1-D launches that cover n_frames frames with gx blocks each.  With xcd_map the
 // hardware's round-robin block->XCD dealing (block b runs on XCD b % 8: observed, used for speed only) is
 // turned into "every block of frame f runs on XCD f % 8", so a frame's bitmap, prefix array, voxel records and
@@ -142,16 +192,12 @@ __global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridP
       }
     }
   }
+  cnt = wave_sum(cnt);
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1)
+  for (int c = 0; c < 3; c++)
   {
-    cnt += __shfl_xor(cnt, s);
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-    {
-      mn[c] = min(mn[c], __shfl_xor(mn[c], s));
-      mx[c] = max(mx[c], __shfl_xor(mx[c], s));
-    }
+    mn[c] = wave_min(mn[c]);
+    mx[c] = wave_max(mx[c]);
   }
   // block-level combine in LDS, then one set of atomics per block
   __shared__ int s_red[4][7];
@@ -309,27 +355,6 @@ __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const Gr
 // ---- exclusive prefix sum of the bitmap's word popcounts (3 phases) ------------------------
 constexpr int SCAN_WPT = 4;                    // words per thread
 constexpr int SCAN_WPB = 256 * SCAN_WPT;       // words per block
-
-// Data-parallel-primitive moves of the gfx9 VALU (no LDS crossbar involved): lanes without a valid source read 0.
-//   0x110 + s: row_shr:s (shift right by s lanes inside each row of 16), 0x142: row_bcast:15 (lane 15 of every row to the
-//   next row), 0x143: row_bcast:31 (lane 31 to the upper half); row_mask selects the rows that take the result.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v)
-{
-  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
-}
-
-// inclusive prefix sum over the 64 lanes of a wave (every lane must be active)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-  v += dpp_mov0<0x111, 0xf>(v);
-  v += dpp_mov0<0x112, 0xf>(v);
-  v += dpp_mov0<0x114, 0xf>(v);
-  v += dpp_mov0<0x118, 0xf>(v);
-  v += dpp_mov0<0x142, 0xa>(v);
-  v += dpp_mov0<0x143, 0xc>(v);
-  return v;
-}
 
 // exclusive scan of one value per thread over a 256-thread block; returns the block total via *total
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds4, uint32_t* total)
