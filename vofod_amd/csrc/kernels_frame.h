@@ -241,6 +241,9 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
       q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
     const bool in_op = inside(q[0], g.op_min[0], g.op_max[0]) & inside(q[1], g.op_min[1], g.op_max[1]) & inside(q[2], g.op_min[2], g.op_max[2]);
     const bool keep = (i0 + j < a.n) & !in_ex & in_op;
+    code[j] = FR_CODE_NONE;
+    if (!__any(keep))
+      continue;  // (wave-uniform) 64 dropped points: whole rings look at the sky
     bool solid = keep;  // survivor whose reference cell is certain
     uint32_t kk[3];
 #pragma unroll
@@ -301,8 +304,11 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   }
   if (threadIdx.x == 0)
   {
-    s_base = total ? atomicAdd(&sa.counts[2 * FRAME], total) : 0u;
-    s_fbase = ftotal ? atomicAdd(&sa.counts[2 * FRAME + 1], ftotal) : 0u;
+    // one returning atomic reserves both lists: the two counters of a frame share a 64-bit word
+    const unsigned long long both =
+        (total | ftotal) ? atomicAdd(reinterpret_cast<unsigned long long*>(&sa.counts[2 * FRAME]), static_cast<unsigned long long>(total) | (static_cast<unsigned long long>(ftotal) << 32)) : 0ull;
+    s_base = static_cast<uint32_t>(both);
+    s_fbase = static_cast<uint32_t>(both >> 32);
     uint32_t tot = 0;
     for (int w = 0; w < KEY2_THREADS / 64; w++)
     {
