@@ -218,8 +218,10 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
       pz[j] = ok ? ldf(a.z, a.stride, i) : 0.0f;
     }
   }
-  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-  int mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
+  // (float minima / maxima per thread, ordered integers from the wave reduction on: the kernel is bound by its vector
+  // instructions, and v_min_f32 on a select is three instructions fewer per axis than the ordered-integer form.  The
+  // sign of a zero bound may differ from the ordered form's; floor(min * inv) - all that is made of it - does not.)
+  float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
   uint32_t code[KEY2_PPT];
   uint32_t cnt = 0, n_surv = 0, frag_mask = 0;
   uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their indices in the cloud
@@ -228,18 +230,25 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   // axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed point, which fails the
   // operation-area test: the explicit isfinite() of the first crop is implied.
   auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
-  const float eps_hi = 1.0f - rl.eps;
-  const float dmax[3] = {static_cast<float>(rl.dims[0] - 1), static_cast<float>(rl.dims[1] - 1), static_cast<float>(rl.dims[2] - 1)};
+  // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop instead of being
+  // copied there in front of every test)
+  float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
+  float eps_hi = 1.0f - rl.eps;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
+  asm volatile("" : "+v"(eps_hi));
+  const uint32_t dlast[3] = {static_cast<uint32_t>(rl.dims[0] - 1), static_cast<uint32_t>(rl.dims[1] - 1), static_cast<uint32_t>(rl.dims[2] - 1)};
 #pragma unroll
   for (int j = 0; j < KEY2_PPT; j++)
   {
     const float p0 = px[j], p1 = py[j], p2 = pz[j];
-    const bool in_ex = inside(p0, g.ex_min[0], g.ex_max[0]) & inside(p1, g.ex_min[1], g.ex_max[1]) & inside(p2, g.ex_min[2], g.ex_max[2]);
+    const bool in_ex = static_cast<int>(inside(p0, g.ex_min[0], ex_hi[0])) & inside(p1, g.ex_min[1], ex_hi[1]) & inside(p2, g.ex_min[2], ex_hi[2]);
     float q[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
       q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
-    const bool in_op = inside(q[0], g.op_min[0], g.op_max[0]) & inside(q[1], g.op_min[1], g.op_max[1]) & inside(q[2], g.op_min[2], g.op_max[2]);
+    const bool in_op = static_cast<int>(inside(q[0], g.op_min[0], op_hi[0])) & inside(q[1], g.op_min[1], op_hi[1]) & inside(q[2], g.op_min[2], op_hi[2]);
     const bool keep = (i0 + j < a.n) & !in_ex & in_op;
     code[j] = FR_CODE_NONE;
     if (!__any(keep))
@@ -249,14 +258,14 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
-      const int o = f2ord(q[c]);  // pcl::getMinMax3D (voxel_grid_weighted.cpp:58)
-      mn[c] = min(mn[c], keep ? o : 0x7fffffff);
-      mx[c] = max(mx[c], keep ? o : static_cast<int>(0x80000000u));
+      // pcl::getMinMax3D (voxel_grid_weighted.cpp:58), as compare + select (fminf would add a canonicalising copy per operand)
+      fmn[c] = (static_cast<int>(keep) & (q[c] < fmn[c])) ? q[c] : fmn[c];
+      fmx[c] = (static_cast<int>(keep) & (q[c] > fmx[c])) ? q[c] : fmx[c];
       const float t = __fmul_rn(__fsub_rn(q[c], rl.off[c]), g.inv[c]);
       const float fl = floorf(t);
       const float fr = __fsub_rn(t, fl);  // exact
-      solid = solid & inside(fr, rl.eps, eps_hi) & inside(fl, 0.0f, dmax[c]);
-      kk[c] = static_cast<uint32_t>(static_cast<int>(fl));
+      kk[c] = static_cast<uint32_t>(static_cast<int>(fl));  // (negative or huge: above every lattice size)
+      solid = solid & inside(fr, rl.eps, eps_hi) & (kk[c] <= dlast[c]);
     }
     n_surv += keep ? 1u : 0u;
     cnt += solid ? 1u : 0u;
@@ -265,11 +274,12 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   }
   // bounding box and survivor count of the block (as k_bbox) ...
   const uint32_t ns = wave_sum(n_surv);
+  int mn[3], mx[3];
 #pragma unroll
   for (int c = 0; c < 3; c++)
   {
-    mn[c] = wave_min(mn[c]);
-    mx[c] = wave_max(mx[c]);
+    mn[c] = wave_min(n_surv ? f2ord(fmn[c]) : 0x7fffffff);
+    mx[c] = wave_max(n_surv ? f2ord(fmx[c]) : static_cast<int>(0x80000000u));
   }
   __shared__ int s_red[KEY2_THREADS / 64][7];
   __shared__ uint32_t s_wsum[KEY2_THREADS / 64], s_fsum[KEY2_THREADS / 64];
@@ -338,11 +348,14 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   for (int j = 0; j < KEY2_PPT; j++)
     if (code[j] != FR_CODE_NONE)
       *out++ = code[j];
-  uint32_t* fout = frag + s_fbase + foff;
+  if (frag_mask)
+  {
+    uint32_t* fout = frag + s_fbase + foff;
 #pragma unroll
-  for (int j = 0; j < KEY2_PPT; j++)
-    if ((frag_mask >> j) & 1u)
-      *fout++ = i0 + j;
+    for (int j = 0; j < KEY2_PPT; j++)
+      if ((frag_mask >> j) & 1u)
+        *fout++ = i0 + j;
+  }
 }
 
 // ---- helpers of k_frame_lds ----------------------------------------------------------------------------------------
@@ -577,13 +590,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     }
     return (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
   };
+  // whole cells between the reference lattice and this frame's: both offsets are floats, their difference times inv lies
+  // within eps of an integer
   int shift[3] = {0, 0, 0};
   if (rl.on)
-  {
-    // whole cells between the reference lattice and this frame's: both offsets are floats, their difference times inv lies
-    // within eps of an integer
     for (int a = 0; a < 3; a++)
       shift[a] = static_cast<int>(rint((static_cast<double>(h.offset[a]) - static_cast<double>(rl.off[a])) * static_cast<double>(g.inv[a])));
+  const int sh0 = shift[0], sh1 = shift[1], sh2 = shift[2];
+  auto ref_code = [&](uint32_t r) -> uint32_t {
+    return cell_code(static_cast<int>(r & 2047u) - sh0, static_cast<int>((r >> 11) & 2047u) - sh1, static_cast<int>(r >> 22) - sh2);
+  };
+  if (rl.on)
+  {
     // the fragile points: exact expression with the frame's own offset (voxel_grid_weighted.cpp:131-136); their codes
     // follow the reference cells in the list
     const uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
@@ -635,11 +653,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         load1(base + FR_THREADS * KPT, cn);  // the next round's codes are on their way while this round works
       if (rl.on)
       {
-        // reference cells -> brick codes of the frame's lattice, written back for the later passes
+        // reference cells -> brick codes of the frame's lattice, written back for the later passes (converting again in
+        // pass 3a instead of writing here was measured: 9 us slower there, 1 us faster here)
 #pragma unroll
         for (int u = 0; u < KPT; u++)
           if (base + u < n_pass1)
-            c[u] = cell_code(static_cast<int>(c[u] & 2047u) - shift[0], static_cast<int>((c[u] >> 11) & 2047u) - shift[1], static_cast<int>(c[u] >> 22) - shift[2]);
+            c[u] = ref_code(c[u]);
         if (vec_ok && base + KPT <= n_pass1)
         {
 #pragma unroll
