@@ -132,12 +132,20 @@ def main():
         tail of one batch overlaps the device chain of the next.  Every batch is submitted and collected inside the call."""
         n_det = 0
         inflight = []
+        host_prof = os.environ.get("VOFOD_BENCH_HOSTPROF") == "1"  # diagnostics: where the host thread spends a step
+        t_sub = t_col = 0.0
         for _ in range(k):
+            ta = time.perf_counter()
             inflight.append(det.batch_submit(scans, tfs))
+            tb = time.perf_counter()
             if len(inflight) == args.inflight:
                 dets, per = det.batch_collect(inflight.pop(0))
                 publish(dets, per)
                 n_det += len(dets)
+            t_sub += tb - ta
+            t_col += time.perf_counter() - tb
+        if host_prof and k > 1:
+            print(f"[host] per step: submit {1e6 * t_sub / k:.0f} us, collect (incl. waiting) {1e6 * t_col / k:.0f} us", file=sys.stderr)
         while inflight:
             dets, per = det.batch_collect(inflight.pop(0))
             publish(dets, per)

@@ -691,6 +691,10 @@ void vofod_destroy(vofod_handle* h)
     (void)hipStreamDestroy(h->stream);
   if (h->stream_tail)
     (void)hipStreamDestroy(h->stream_tail);
+  if (h->stream_key)
+    (void)hipStreamDestroy(h->stream_key);
+  if (h->stream_frame)
+    (void)hipStreamDestroy(h->stream_frame);
   for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
     if (h->chain_stream[t])
       (void)hipStreamDestroy(h->chain_stream[t]);
@@ -732,6 +736,9 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     CREATE_CHK(hipStreamCreateWithPriority(&h->stream_tail, hipStreamNonBlocking, prio_hi));
+    // staged pipeline of submitted batches (process_frames): streaming kernels below the frame kernels
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_key, hipStreamNonBlocking, prio_lo));
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frame, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
   }
   h->chain_stream[0] = h->stream;
   for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)

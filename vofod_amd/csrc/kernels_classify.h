@@ -54,7 +54,7 @@ struct ExploreParams
 __device__ __forceinline__ uint32_t pack_rel(int dx, int dy, int dz) { return static_cast<uint32_t>((dx + 128) | ((dy + 128) << 8) | ((dz + 128) << 16)); }
 
 // one wave (64 threads) per frame with jobs; job_begin[f]..job_end[f] index that frame's jobs in order
-__global__ __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin, const uint32_t* __restrict__ job_end,
+__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin, const uint32_t* __restrict__ job_end,
                                                 const int* __restrict__ members, float* __restrict__ map, unsigned long long* __restrict__ overlay_all,
                                                 uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all,
                                                 uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all)

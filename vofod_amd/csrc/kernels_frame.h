@@ -501,7 +501,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint32_t s_cflag[FR_CHUNKS + 1];
   __shared__ uint32_t s_wsum[FR_THREADS / 64];
   __shared__ uint32_t s_n, s_nh, s_nn, s_nf, s_no, s_ne;
-  __shared__ uint32_t s_segc[2][FR_THREADS / 64];  // fill levels of the waves' hit-list segments
   unsigned long long* s_bits64 = s_bb;
   uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
   uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
@@ -1179,14 +1178,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   const uint32_t hcap = g.vox_cap * 5u;
   uint32_t* opens = hits + hcap;
   // Adjacent bricks first: face neighbours (<= 3 per brick in the half stencil) and the other adjacent bricks (<= 10) go to
-  // two hit lists.  Every wave fills a segment of its own in each list (its fill level is a wave-uniform register: ballots
-  // place the hits, no scan, no atomic).  Bricks two apart are looked at after these have been merged - and then only
-  // around the bricks outside the largest component (D-a2 below): a pair inside one component has nothing left to decide.
-  constexpr uint32_t FR_WAVES = FR_THREADS / 64;
-  const uint32_t bpw = (64u / LB_LANES) * ((n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES));  // bricks a wave serves at most
-  const uint32_t seg_axis = 3u * bpw, seg_near = 10u * bpw;
-  const uint32_t cap_axis = FR_WAVES * seg_axis, cap_near = FR_WAVES * seg_near;
-  if (hcap < cap_axis + cap_near + n)
+  // two hit lists.  Bricks two apart are looked at after these have been merged - and then only around the bricks outside
+  // the largest component (D-a2 below): a pair inside one component has nothing left to decide.
+  const uint32_t cap_axis = 3u * n, cap_near = 10u * n;
+  if (hcap < 14u * n)
   {
     if (tid == 0)
     {
@@ -1266,11 +1261,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
     const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
-    uint32_t fillA = 0, fillN = 0;  // wave-uniform
-    uint32_t* segA = hits + wave * seg_axis;
-    uint32_t* segN = hits_near + wave * seg_near;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the ballots below span the wave
+    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservations below scan the wave
     {
       const bool live = t < n;
       const uint32_t xyz = live ? s_xyz[t] : 0u;
@@ -1279,32 +1270,34 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       int shw = 0;
       if (live && valid && ny >= 0 && ny < nby && nz < nbz)
         win = window(bx, ny, nz, raw, nb0, shw) & valid;
-      if (!__any(win != 0u))
-        continue;
-#pragma unroll
-      for (int q = 0; q < 3; q++)  // the adjacent slots: dx = -1, 0, +1
+      // one reservation per wave and list
+      const uint32_t kA = __popc(win & axis), kN = __popc(win & ~axis);
+      const uint32_t iA = wave_incl_scan(kA), iN = wave_incl_scan(kN);
+      uint32_t bA = 0, bN = 0;
+      if (lane == 63)
       {
-        const int sl = R - 1 + q;
-        const bool hit = (win >> sl) & 1u, ax = (axis >> sl) & 1u;
-        const unsigned long long mA = __ballot(hit && ax), mN = __ballot(hit && !ax);
-        if (hit)
-        {
-          const uint32_t o = static_cast<uint32_t>(ov >> (8 * sl)) & 0xffu;
-          const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
-          uint32_t* dst = ax ? segA + fillA + __popcll(mA & below) : segN + fillN + __popcll(mN & below);
-          *dst = t | (t2 << 13) | (o << 26);
-        }
-        fillA += static_cast<uint32_t>(__popcll(mA));
-        fillN += static_cast<uint32_t>(__popcll(mN));
+        if (iA)
+          bA = atomicAdd(&s_nh, iA);
+        if (iN)
+          bN = atomicAdd(&s_nn, iN);
       }
-    }
-    if (lane == 0)
-    {
-      s_segc[0][wave] = fillA;
-      s_segc[1][wave] = fillN;
+      uint32_t pA = __builtin_amdgcn_readlane(bA, 63) + iA - kA, pN = __builtin_amdgcn_readlane(bN, 63) + iN - kN;
+      while (win)
+      {
+        const int sl = __ffs(static_cast<int>(win)) - 1;
+        win &= win - 1;
+        const uint32_t o = static_cast<uint32_t>(ov >> (8 * sl)) & 0xffu;
+        const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+        const uint32_t hv = t | (t2 << 13) | (o << 26);
+        if ((axis >> sl) & 1u)
+          hits[pA++] = hv;
+        else
+          hits_near[pN++] = hv;
+      }
     }
   }
   __syncthreads();
+  const uint32_t nh_axis = s_nh, nh_near = s_nn;
   FR_STAMP(8);
   auto link = [&](uint32_t ra, uint32_t rb) {  // hook the larger root under the smaller (labels: smallest member)
     while (ra != rb)
@@ -1341,26 +1334,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     __syncthreads();
   };
   constexpr int HU = 8;
-  // a list is n_seg segments of seg_cap entries, filled to cnt[]; a lane takes a chunk of HU consecutive hits of one
-  // segment: they mostly share the brick t (the lists are in D-a's order), whose root is then found once
-  auto hits_pass = [&](const uint32_t* __restrict__ base_list, const uint32_t n_seg, const uint32_t seg_cap, const uint32_t* cnt) {
-    uint32_t pre[FR_WAVES + 1];  // chunks before segment w
-    pre[0] = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < FR_WAVES; w++)
-      pre[w + 1] = pre[w] + (w < n_seg ? (cnt[w] + HU - 1) / HU : 0u);
-    for (uint32_t ck = tid; ck < pre[FR_WAVES]; ck += FR_THREADS)
+  auto hits_pass = [&](const uint32_t* __restrict__ list, const uint32_t nh) {
+    // a lane takes HU consecutive hits: they mostly share the brick t (the list is in D-a's order), whose root is then found once
+    for (uint32_t i0 = tid * HU; i0 < nh; i0 += FR_THREADS * HU)
     {
-      uint32_t seg = 0;
-#pragma unroll
-      for (uint32_t w = 1; w < FR_WAVES; w++)
-        seg += ck >= pre[w] ? 1u : 0u;
-      uint32_t first = 0;
-#pragma unroll
-      for (uint32_t w = 1; w < FR_WAVES; w++)
-        first = seg == w ? pre[w] : first;
-      const uint32_t i0 = (ck - first) * HU, nh = cnt[seg];
-      const uint32_t* list = base_list + seg * seg_cap;
       uint32_t hv[HU], da[HU], db[HU];
       bool act[HU];
 #pragma unroll
@@ -1426,10 +1403,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
   };
-  hits_pass(hits, FR_WAVES, seg_axis, s_segc[0]);
+  hits_pass(hits, nh_axis);
   __syncthreads();
   flatten();
-  hits_pass(hits_near, FR_WAVES, seg_near, s_segc[1]);
+  hits_pass(hits_near, nh_near);
   __syncthreads();
   flatten();
   FR_STAMP(9);
@@ -1531,13 +1508,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     }
     return;
   }
-  hits_pass(hits_far, 1u, 0u, &s_nf);
+  hits_pass(hits_far, nh_far);
   __syncthreads();
   flatten();
   const uint32_t no = s_no;
-  uint32_t nh = nh_far;
-  for (uint32_t w = 0; w < FR_WAVES; w++)
-    nh += s_segc[0][w] + s_segc[1][w];
+  const uint32_t nh = nh_axis + nh_near + nh_far;
   FR_STAMP(10);
   // D-c: keep the open pairs whose ends still sit in different components (roots after the flatten) ...
   if (tid == 0)

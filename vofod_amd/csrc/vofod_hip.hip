@@ -5,6 +5,7 @@
 // classification tail (host_tail.h) on the few candidate clusters.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -220,6 +221,22 @@ struct Prof
       hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);    \
   } while (0)
 
+// (the same with dynamic LDS)
+#define KLAUNCH_LDS(h, kern, grid, block, lds, ...)                                   \
+  do                                                                         \
+  {                                                                          \
+    if ((h)->prof.on)                                                        \
+    {                                                                        \
+      Prof::Rec r_{#kern, (h)->prof.get(), (h)->prof.get()};                 \
+      (void)hipEventRecord(r_.a, (h)->stream);                               \
+      hipLaunchKernelGGL(kern, grid, block, lds, (h)->stream, __VA_ARGS__);    \
+      (void)hipEventRecord(r_.b, (h)->stream);                               \
+      (h)->prof.recs.push_back(r_);                                          \
+    }                                                                        \
+    else                                                                     \
+      hipLaunchKernelGGL(kern, grid, block, lds, (h)->stream, __VA_ARGS__);    \
+  } while (0)
+
 struct Workspace
 {
   uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0, bricks_cap = 0;
@@ -288,6 +305,7 @@ struct Workspace
   std::vector<float> job_tfs;
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev_packed = nullptr;   // the read-back slots are complete on the chain's stream
+  hipEvent_t ev_key = nullptr;      // staged pipeline: the batch's streaming kernels (brick codes) are through
   hipStream_t copy_stream = nullptr;  // device-to-host copy of the slots: the chain's stream goes on with the next batch meanwhile
 
   void release()
@@ -308,6 +326,8 @@ struct Workspace
       (void)hipEventDestroy(ev_done);
     if (ev_packed)
       (void)hipEventDestroy(ev_packed);
+    if (ev_key)
+      (void)hipEventDestroy(ev_key);
     if (copy_stream)
       (void)hipStreamDestroy(copy_stream);
     *this = Workspace();
@@ -390,6 +410,8 @@ struct Workspace
       return e;
     if ((e = hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)) != hipSuccess)
       return e;
+    if ((e = hipEventCreateWithFlags(&ev_key, hipEventDisableTiming)) != hipSuccess)
+      return e;
     if ((e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)) != hipSuccess)
       return e;
     // the memsets above run on the null stream, the kernels on non-blocking streams: wait for the fills to land
@@ -430,6 +452,8 @@ struct vofod_handle
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream_tail = nullptr;  // tail (k_explore) of collected async batches
+  hipStream_t stream_key = nullptr;   // staged pipeline: streaming kernels of all submitted batches, lowest priority
+  hipStream_t stream_frame = nullptr; // staged pipeline: frame kernels of all submitted batches
   static constexpr int MAX_INFLIGHT = 4;
   hipStream_t chain_stream[MAX_INFLIGHT] = {nullptr, nullptr, nullptr, nullptr};  // [0] == stream; in-flight batches run their chains on separate streams and overlap on the device
   Workspace wsx[MAX_INFLIGHT - 1];                                                  // workspaces of tickets 1..3 (ticket 0 uses ws)
@@ -1616,11 +1640,29 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   static const int two_chains_env = std::getenv("VOFOD_TWO_CHAINS") ? std::atoi(std::getenv("VOFOD_TWO_CHAINS")) : -1;
   static const bool stagger_on = !(std::getenv("VOFOD_STAGGER") && std::atoi(std::getenv("VOFOD_STAGGER")) == 0);
   const bool two_chains = two_chains_env >= 0 ? two_chains_env != 0 : true;
+  // Submitted batches run as a three-stage pipeline on three streams: the streaming kernels (bounding box + brick codes:
+  // vector-instruction bound, a few waves per CU) of every batch on a low-priority stream, the frame kernels (one 156 KB
+  // workgroup per CU, latency bound) on a second one, the classification tails on a third (high priority).  The streaming
+  // kernels of batch k+1 then fill the issue slots the frame kernel of batch k leaves idle, and when both are ready at the
+  // same moment the frame kernel's workgroups are placed first (a CU full of streaming waves has no room for one).
+  // VOFOD_PIPE=ticket: a stream per ticket (round 2's first scheme: chains of queued batches start as they are submitted).
+  static const bool per_ticket_streams = std::getenv("VOFOD_PIPE") && std::string(std::getenv("VOFOD_PIPE")) == "ticket";
   hipStream_t my_stream = nullptr;
+  bool staged = false;
   if (two_chains && phase == FRAMES_LAUNCH)
-    for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
-      if (&ws == h->slot(t))
-        my_stream = h->chain_stream[t];
+  {
+    if (per_ticket_streams || !h->stream_key || !h->stream_frame)
+    {
+      for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
+        if (&ws == h->slot(t))
+          my_stream = h->chain_stream[t];
+    }
+    else
+    {
+      my_stream = h->stream_key;
+      staged = true;
+    }
+  }
   if (phase != FRAMES_COLLECT)
   {
   ChainStream chain_guard(h, my_stream);
@@ -1699,6 +1741,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     return r;
   if (dbg)
     HIPCHK(hipEventRecord(ev[1], h->stream));
+  if (staged)
+  {
+    HIPCHK(hipEventRecord(ws.ev_key, h->stream));
+    h->stream = h->stream_frame;
+    HIPCHK(hipStreamWaitEvent(h->stream, ws.ev_key, 0));
+  }
 
   // ---- K7 clusterCloud :932
   UpdateParams up{};
@@ -1744,6 +1792,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   static const bool dtail_on = !(std::getenv("VOFOD_DEVICE_TAIL") && std::atoi(std::getenv("VOFOD_DEVICE_TAIL")) == 0);
   ws.dtail = dtail_on && !dbg && n >= 4 && no_update;
   ws.lite = !ws.dtail && lite_on && !dbg && n >= 4 && no_update;
+  hipStream_t tail_stream_used = h->stream;  // where the device tail's last operation was enqueued
   if (ws.dtail)
   {
     // Classification tail on the device (kernels_tail.h): boxes + gates, flood fills, detection records; nothing comes back
@@ -1804,14 +1853,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
             eb.d_ovl_count, eb.d_results, eb.d_visited);
     KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets);
     HIPCHK(hipEventRecord(h->ev_explore, h->stream));
-    if (phase == FRAMES_LAUNCH)
-    {
-      HIPCHK(hipEventRecord(ws.ev_packed, h->stream));
-      HIPCHK(hipStreamWaitEvent(ws.copy_stream, ws.ev_packed, 0));
-      HIPCHK(hipMemcpyAsync(ws.h_dets, ws.d_dets, sizeof(vtd::FrameDets) * n, hipMemcpyDeviceToHost, ws.copy_stream));
-    }
-    else
-      HIPCHK(hipMemcpyAsync(ws.h_dets, ws.d_dets, sizeof(vtd::FrameDets) * n, hipMemcpyDeviceToHost, h->stream));
+    // the records come back on the tail stream itself (135 KB): a copy stream per workspace would share a hardware queue
+    // with one of the pipeline's streams, and a copy waiting there for its tail holds up the kernels queued behind it
+    HIPCHK(hipMemcpyAsync(ws.h_dets, ws.d_dets, sizeof(vtd::FrameDets) * n, hipMemcpyDeviceToHost, h->stream));
+    tail_stream_used = h->stream;
   }
   else if (ws.lite)
   {
@@ -1835,7 +1880,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   tr_launch = ms_since(t0);
   if (phase == FRAMES_LAUNCH)
   {
-    HIPCHK(hipEventRecord(ws.ev_done, (ws.lite || ws.dtail) ? ws.copy_stream : h->stream));
+    HIPCHK(hipEventRecord(ws.ev_done, ws.dtail ? tail_stream_used : ws.lite ? ws.copy_stream : h->stream));
     ws.pending = true;
     ws.job_n = n;
     ws.job_g = g;
