@@ -34,6 +34,9 @@ namespace vk
 
 constexpr int FR_THREADS = 1024;
 constexpr int FR_BW64 = LB_BITWORDS / 2;  // 64-bit words of the brick-lattice bitmap
+#ifndef FR_WAVE_PRIO
+#define FR_WAVE_PRIO 3
+#endif
 constexpr int FR_EREC = LB_MAX / 2;       // extras records kept in LDS (they share the union-find's storage)
 constexpr int FR_CHUNKS = LB_MAX / 64;    // 64-node chunks of the rank scans
 constexpr int FR_MAX_NBZ = 64;            // brick layers along z
@@ -507,6 +510,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bits64);
   uint16_t* s_vbase = reinterpret_cast<uint16_t*>(s_x2);  // node -> index of its first voxel in brick order (counting / rank phases)
   uint16_t* s_par = reinterpret_cast<uint16_t*>(s_x2);
+  // the streaming kernels of the next batch run beside this kernel (process_frames' pipeline): this kernel's waves are the
+  // critical path and go first wherever both want to issue
+  __builtin_amdgcn_s_setprio(FR_WAVE_PRIO);
   const uint32_t FRAME = blockIdx.x;
   FrameHdr& h = hdrs[FRAME];
   // single-pass input (k_key1): the list holds reference cells, the fragile points wait beside it with their coordinates
