@@ -188,6 +188,10 @@ struct RefLattice
   int32_t on;
 };
 
+#ifndef KEY1_PPT_DEF
+#define KEY1_PPT_DEF 8
+#endif
+constexpr int KEY1_PPT = KEY1_PPT_DEF;  // consecutive points per thread of k_key1 (a multiple of 4)
 template <bool PACKED>
 __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
 {
@@ -196,23 +200,27 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
     return;
   (void)GX;
   const FrameArgs a = args[FRAME];  // (a copy: the transform stays in scalar registers)
-  const uint32_t base_blk = BX * KEY2_THREADS * KEY2_PPT;
+  const uint32_t base_blk = BX * KEY2_THREADS * KEY1_PPT;
   if (base_blk >= a.n)
     return;
-  const uint32_t i0 = base_blk + threadIdx.x * KEY2_PPT;
-  float px[KEY2_PPT], py[KEY2_PPT], pz[KEY2_PPT];
-  if (PACKED && i0 + KEY2_PPT <= a.n)
+  const uint32_t i0 = base_blk + threadIdx.x * KEY1_PPT;
+  float px[KEY1_PPT], py[KEY1_PPT], pz[KEY1_PPT];
+  if (PACKED && i0 + KEY1_PPT <= a.n)
   {
     const char *cx = a.x + static_cast<uint64_t>(i0) * 4, *cy = a.y + static_cast<uint64_t>(i0) * 4, *cz = a.z + static_cast<uint64_t>(i0) * 4;
-    const float4 x0 = ldg_f4(cx), x1 = ldg_f4(cx + 16), y0 = ldg_f4(cy), y1 = ldg_f4(cy + 16), z0 = ldg_f4(cz), z1 = ldg_f4(cz + 16);
-    px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
-    py[0] = y0.x, py[1] = y0.y, py[2] = y0.z, py[3] = y0.w, py[4] = y1.x, py[5] = y1.y, py[6] = y1.z, py[7] = y1.w;
-    pz[0] = z0.x, pz[1] = z0.y, pz[2] = z0.z, pz[3] = z0.w, pz[4] = z1.x, pz[5] = z1.y, pz[6] = z1.z, pz[7] = z1.w;
+#pragma unroll
+    for (int q = 0; q < KEY1_PPT / 4; q++)
+    {
+      const float4 x0 = ldg_f4(cx + 16 * q), y0 = ldg_f4(cy + 16 * q), z0 = ldg_f4(cz + 16 * q);
+      px[4 * q] = x0.x, px[4 * q + 1] = x0.y, px[4 * q + 2] = x0.z, px[4 * q + 3] = x0.w;
+      py[4 * q] = y0.x, py[4 * q + 1] = y0.y, py[4 * q + 2] = y0.z, py[4 * q + 3] = y0.w;
+      pz[4 * q] = z0.x, pz[4 * q + 1] = z0.y, pz[4 * q + 2] = z0.z, pz[4 * q + 3] = z0.w;
+    }
   }
   else
   {
 #pragma unroll
-    for (int j = 0; j < KEY2_PPT; j++)
+    for (int j = 0; j < KEY1_PPT; j++)
     {
       const uint32_t i = i0 + j;
       const bool ok = i < a.n;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   // instructions, and v_min_f32 on a select is three instructions fewer per axis than the ordered-integer form.  The
   // sign of a zero bound may differ from the ordered form's; floor(min * inv) - all that is made of it - does not.)
   float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  uint32_t code[KEY2_PPT];
+  uint32_t code[KEY1_PPT];
   uint32_t cnt = 0, n_surv = 0, frag_mask = 0;
   uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their indices in the cloud
   // Branch-free per point (the kernel was bound by the scalar unit's exec-mask bookkeeping, not by its float work): a value
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   asm volatile("" : "+v"(eps_hi));
   const uint32_t dlast[3] = {static_cast<uint32_t>(rl.dims[0] - 1), static_cast<uint32_t>(rl.dims[1] - 1), static_cast<uint32_t>(rl.dims[2] - 1)};
 #pragma unroll
-  for (int j = 0; j < KEY2_PPT; j++)
+  for (int j = 0; j < KEY1_PPT; j++)
   {
     const float p0 = px[j], p1 = py[j], p2 = pz[j];
     const bool in_ex = static_cast<int>(inside(p0, g.ex_min[0], ex_hi[0])) & inside(p1, g.ex_min[1], ex_hi[1]) & inside(p2, g.ex_min[2], ex_hi[2]);
@@ -348,14 +356,14 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   // ... and the reference cells of its (non-fragile) survivors, in point order
   uint32_t* out = sa.keys + static_cast<size_t>(FRAME) * pt_cap + s_base + off;
 #pragma unroll
-  for (int j = 0; j < KEY2_PPT; j++)
+  for (int j = 0; j < KEY1_PPT; j++)
     if (code[j] != FR_CODE_NONE)
       *out++ = code[j];
   if (frag_mask)
   {
     uint32_t* fout = frag + s_fbase + foff;
 #pragma unroll
-    for (int j = 0; j < KEY2_PPT; j++)
+    for (int j = 0; j < KEY1_PPT; j++)
       if ((frag_mask >> j) & 1u)
         *fout++ = i0 + j;
   }

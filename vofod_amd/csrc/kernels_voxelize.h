@@ -140,9 +140,11 @@ __device__ __forceinline__ uint32_t cell_key(const FrameHdr& h, const GridParams
   return static_cast<uint32_t>(i0 + i1 * h.div_b[0] + i2 * h.div_b[0] * h.div_b[1]);
 }
 
-__global__ void k_init_hdr(FrameHdr* hdrs)
+__global__ void k_init_hdr(FrameHdr* hdrs, uint32_t* counts2)
 {
   FrameHdr& h = hdrs[blockIdx.x];
+  if (counts2 && threadIdx.x < 2)
+    counts2[2 * blockIdx.x + threadIdx.x] = 0;  // the frame's two list counters of k_key1 (one kernel less in the chain than a memset)
   if (threadIdx.x == 0)
   {
     for (int a = 0; a < 3; a++)

@@ -987,13 +987,13 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   const uint32_t lean_bit = ws.lean_emit ? 0x80000000u : 0u;
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
-  KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs);
   const uint32_t gb = std::max(1u, std::min((max_pts + 2047u) / 2048u, 1024u));  // 8 points per thread: few header atomics
   static const bool frame_on = !(std::getenv("VOFOD_FRAME_LDS") && std::atoi(std::getenv("VOFOD_FRAME_LDS")) == 0);
   const bool frame_plan = frame_on && ws.lean_emit && n >= 4 && !want_ptrank && !two_phase;
   ws.ref_lattice = RefLattice{};
   if (frame_plan)
     ws.ref_lattice = fill_ref_lattice(g);
+  KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs, (frame_plan && ws.ref_lattice.on) ? ws.sa.counts : nullptr);
   bool packed = frame_plan;
   for (uint32_t f = 0; f < n && packed; f++)
   {
