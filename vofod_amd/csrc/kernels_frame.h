@@ -512,6 +512,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint32_t s_cflag[FR_CHUNKS + 1];
   __shared__ uint32_t s_wsum[FR_THREADS / 64];
   __shared__ uint32_t s_n, s_nh, s_nn, s_nf, s_no, s_ne;
+  __shared__ uint32_t s_nhn;  // both adjacent-hit counters of the probe: face neighbours << 17 | others (<= 3 and 10 per brick)
   unsigned long long* s_bits64 = s_bb;
   uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
   uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   {
     s_ne = 0;
     s_nh = 0;
+    s_nhn = 0;
     s_nn = 0;
     s_nf = 0;
     s_no = 0;
@@ -1284,34 +1286,51 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       int shw = 0;
       if (live && valid && ny >= 0 && ny < nby && nz < nbz)
         win = window(bx, ny, nz, raw, nb0, shw) & valid;
-      // one reservation per wave and list
-      const uint32_t kA = __popc(win & axis), kN = __popc(win & ~axis);
-      const uint32_t iA = wave_incl_scan(kA), iN = wave_incl_scan(kN);
-      uint32_t bA = 0, bN = 0;
-      if (lane == 63)
+      if (!__any(win != 0u))
+        continue;
+      // One reservation per wave for both lists: ballots count the hits of the three adjacent slots (dx = -1, 0, +1), one LDS
+      // atomic on the packed counter (face-neighbour hits in the upper 15 bits, the others in the lower 17) hands out the
+      // space, and every hit's place follows from the ballots - no scan, no loop over the window.
+      unsigned long long mA[3], mN[3];
+      uint32_t totA = 0, totN = 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
       {
-        if (iA)
-          bA = atomicAdd(&s_nh, iA);
-        if (iN)
-          bN = atomicAdd(&s_nn, iN);
+        const int sl = R - 1 + q;
+        const bool hit = (win >> sl) & 1u, ax = (axis >> sl) & 1u;
+        mA[q] = __ballot(hit && ax);
+        mN[q] = __ballot(hit && !ax);
+        totA += static_cast<uint32_t>(__popcll(mA[q]));
+        totN += static_cast<uint32_t>(__popcll(mN[q]));
       }
-      uint32_t pA = __builtin_amdgcn_readlane(bA, 63) + iA - kA, pN = __builtin_amdgcn_readlane(bN, 63) + iN - kN;
-      while (win)
+      static_assert(3 * LB_MAX < (1 << 15) && 10 * LB_MAX < (1 << 17), "fields of the packed hit counter");
+      uint32_t base = 0;
+      if (lane == 0)
+        base = atomicAdd(&s_nhn, (totA << 17) | totN);
+      base = __builtin_amdgcn_readfirstlane(base);
+      uint32_t pA = base >> 17, pN = base & 0x1ffffu;
+      const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
       {
-        const int sl = __ffs(static_cast<int>(win)) - 1;
-        win &= win - 1;
-        const uint32_t o = static_cast<uint32_t>(ov >> (8 * sl)) & 0xffu;
-        const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
-        const uint32_t hv = t | (t2 << 13) | (o << 26);
-        if ((axis >> sl) & 1u)
-          hits[pA++] = hv;
-        else
-          hits_near[pN++] = hv;
+        const int sl = R - 1 + q;
+        if ((win >> sl) & 1u)
+        {
+          const uint32_t o = static_cast<uint32_t>(ov >> (8 * sl)) & 0xffu;
+          const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+          const uint32_t hv = t | (t2 << 13) | (o << 26);
+          if ((axis >> sl) & 1u)
+            hits[pA + __popcll(mA[q] & below)] = hv;
+          else
+            hits_near[pN + __popcll(mN[q] & below)] = hv;
+        }
+        pA += static_cast<uint32_t>(__popcll(mA[q]));
+        pN += static_cast<uint32_t>(__popcll(mN[q]));
       }
     }
   }
   __syncthreads();
-  const uint32_t nh_axis = s_nh, nh_near = s_nn;
+  const uint32_t nh_axis = s_nhn >> 17, nh_near = s_nhn & 0x1ffffu;
   FR_STAMP(8);
   auto link = [&](uint32_t ra, uint32_t rb) {  // hook the larger root under the smaller (labels: smallest member)
     while (ra != rb)
