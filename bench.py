@@ -238,6 +238,14 @@ def main():
                                     "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU; one workgroup per frame leaves 7/8 of the CUs idle in k_frame_lds"}
         if not args.no_profile_pass:
             out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F)
+            # the same bytes over the pipelined step time of this rank (kernels of consecutive batches overlap: the step is
+            # shorter than the sum of its kernels)
+            pb = out["roofline"]["path"]["alg_bytes_per_batch"]
+            out["roofline"]["path"]["pipelined"] = {
+                "us_per_batch": 1e3 * out["ms_per_step"],
+                "GBps": pb / (1e-3 * out["ms_per_step"]) / 1e9,
+                "frac": pb / (1e-3 * out["ms_per_step"]) / 1e9 / HBM_PEAK_GBS,
+            }
         if args.cpu_baseline_scans > 0:
             out["cpu_baseline"] = cpu_baseline(args, det, host_scans)
     sync()
@@ -269,6 +277,8 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
     alg = {
         # batched fast path (kernels_frame.h)
         "k_bbox": 12.0 * n_pts * F,          # bounding box: one read of the xyz columns
+        "k_key1<true>": 12.0 * n_pts * F,    # single pass over the xyz columns: bounding box + reference cells
+        "k_key1<false>": 12.0 * n_pts * F,
         "k_key2<true>": 12.0 * n_pts * F,    # brick codes: the second read of the same columns (counted again here, once in the path total)
         "k_key2<false>": 12.0 * n_pts * F,
         "k_frame_lds": 40.0 * V * F,         # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
