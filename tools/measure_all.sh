@@ -7,7 +7,7 @@ TAG=${1:-r02}
 set -o pipefail
 mkdir -p gpurun_out/${TAG}_summary
 tools/run_profiles.sh ${TAG} > gpurun_out/${TAG}_profiles.log 2>&1; tail -2 gpurun_out/${TAG}_profiles.log
-cp profiles/${TAG}_kernel_stats*.csv profiles/${TAG}_traffic.json gpurun_out/${TAG}_summary/
+cp profiles/${TAG}_kernel_stats*.csv profiles/${TAG}_traffic.json profiles/${TAG}_timeline_pipelined.txt gpurun_out/${TAG}_summary/
 timeout -k 10 400 python bench.py > gpurun_out/${TAG}_summary/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 python -c "
 import json;d=json.load(open('gpurun_out/${TAG}_summary/${TAG}_bench_default.json'));r=d['roofline'];print(round(d['value']),round(d['ms_per_step'],3),round(r['frac'],4),r['traffic'],round(r['path']['frac'],4),round(r['path']['pipelined']['frac'],4),d['cpu_baseline']['value'],d.get('config3_share'))"

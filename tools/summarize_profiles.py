@@ -27,7 +27,7 @@ def main():
             for r in rows:
                 f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
     # The profiled command warms the map with single-scan launches before the batched steps; the bench line is about
-    # the batched launches, so a second table restricts every kernel to its largest grid (= the 32-frame launches).
+    # the batched launches, so a second table restricts every kernel to its largest grid (= the full-batch launches).
     trace = glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True)
     if trace:
         per = defaultdict(list)

@@ -1652,7 +1652,9 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   bool staged = false;
   if (two_chains && phase == FRAMES_LAUNCH)
   {
-    if (per_ticket_streams || !h->stream_key || !h->stream_frame)
+    // (a batch that leaves most CUs idle - fewer frames than half the CUs - gains more from whole chains running side by
+    // side: its frame kernel shares the chip with the frame kernels of the other batches in flight)
+    if (per_ticket_streams || !h->stream_key || !h->stream_frame || n < 128u)
     {
       for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
         if (&ws == h->slot(t))
