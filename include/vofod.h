@@ -266,10 +266,13 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
                         vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out,
                         vofod_scan_debug* dbg);
 
-/* The same, pipelined: submit enqueues the kernel chain of a batch on its own stream and returns a ticket (0..3; at most four
- * batches in flight, their chains overlap on the device), collect waits for it, runs the classification tail and returns the detections.  Submitting batch k+1
- * before collecting batch k hides the host-side tail behind the device work of the next batch.  Read-only map only
- * (VOFOD_SCAN_NO_MAP_UPDATE semantics); collect in submit order for deterministic detection ids. */
+/* The same, pipelined: submit enqueues the kernels of a batch and returns a ticket (0..3; at most four batches in flight:
+ * streaming kernels, frame kernels and classification tails of consecutive batches run as a three-stage pipeline on the
+ * device), collect waits for it and returns the detections.  Submitting batch k+1 (and k+2) before collecting batch k keeps
+ * the pipeline full.  Read-only map only (VOFOD_SCAN_NO_MAP_UPDATE semantics); collect in submit order for deterministic
+ * detection ids.  The scans' host buffers need not outlive submit.  collect with an `out` too small for the batch returns
+ * VOFOD_ERR_CAPACITY with *n_out = the detections to make room for; the ticket then stays pending and no ids are handed out
+ * (batches of >= 4 frames; a batch that had to take the host tail is consumed by the failing call). */
 int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket);
 int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out);
 

@@ -4,6 +4,8 @@ Bar (north_star): bit-exact voxel indices, weights, centres, cluster membership,
 and map contents after integer/byte-exact stages; stated tolerances on OBB-derived positions, confidences
 and on everything downstream of the float-atomic raycast accumulation.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -461,6 +463,35 @@ def test_pipelined_batches_equal_synchronous(oracle, hip):
         assert_detections_equal(wd, gd)
     with pytest.raises(Exception):
         dev.batch_collect(0)
+
+
+def test_collect_with_too_small_an_array_keeps_the_ticket(oracle, hip):
+    """vofod_batch_collect with an `out` too small: VOFOD_ERR_CAPACITY, *n_out = the size needed, the ticket stays pending and
+    the second call returns what the synchronous call returns (ids included: none were handed out by the failing call)"""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=4)
+    scene = synth.make_scene(21, n_targets=3)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+        for s in synth.scan_sequence(scene, "os1-128", 5, seed0=300):
+            d.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+    sync_maps(ref, dev)
+    b = synth.scan_sequence(scene, "os1-128", 4, seed0=310)
+    scans, tfs = [s.scan for s in b], np.stack([s.tf for s in b])
+    wd, wp = ref.process_batch(scans, tfs)
+    assert len(wd) >= 2
+    t = dev.batch_submit(scans, tfs)
+    small = np.zeros(1, dtype=capi.DETECTION)
+    per = np.zeros(4, dtype=np.uint32)
+    n_out = C.c_size_t(0)
+    assert dev.lib.batch_collect(dev.h, t, capi.ptr(small), 1, capi.ptr(per), C.byref(n_out)) == capi.ERR_CAPACITY
+    assert n_out.value == len(wd)
+    gd, gp = dev.batch_collect(t, det_cap=1)  # the wrapper comes back with the size asked for
+    np.testing.assert_array_equal(gp, wp)
+    gd = gd.copy()
+    gd["id"] += wd["id"][0] - gd["id"][0]
+    assert_detections_equal(wd, gd)
+    assert np.all(np.diff(gd["id"]) == 1)
 
 
 def test_dynamic_params_invalidate_cached_tables(oracle, hip):

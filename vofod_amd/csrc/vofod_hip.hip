@@ -1966,6 +1966,20 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     if (!fb)
     {
       size_t total = 0;
+      if (phase == FRAMES_COLLECT && out)
+      {
+        // an output array too small for this batch: nothing is consumed - the ticket stays pending, ids are not handed
+        // out, *n_out tells the size to come back with
+        size_t need = 0;
+        for (uint32_t f = 0; f < n; f++)
+          need += ws.h_dets[f].n;
+        if (need > cap)
+        {
+          ws.pending = true;
+          *n_out = need;
+          return VOFOD_ERR_CAPACITY;
+        }
+      }
       for (uint32_t f = 0; f < n; f++)
       {
         const vtd::FrameDets& D = ws.h_dets[f];

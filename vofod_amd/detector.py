@@ -241,14 +241,25 @@ class VoFOD:
 
     def batch_collect(self, ticket: int, det_cap: int = 4096):
         n = self._pending.pop(ticket)
-        buf = self._collect_bufs.get((det_cap, n))  # reused between calls: the results are copied out below
-        if buf is None:
-            buf = (np.zeros(det_cap, dtype=capi.DETECTION), np.zeros(n, dtype=np.uint32))
-            self._collect_bufs[(det_cap, n)] = buf
-        dets, per = buf
-        n_out = C.c_size_t(0)
-        self._check(self.lib.batch_collect(self.h, ticket, capi.ptr(dets), det_cap, capi.ptr(per), C.byref(n_out)), "vofod_batch_collect")
-        return dets[: n_out.value].copy(), per.copy()
+        for attempt in (0, 1):
+            buf = self._collect_bufs.get((det_cap, n))  # reused between calls: the results are copied out below
+            if buf is None:
+                buf = (np.zeros(det_cap, dtype=capi.DETECTION), np.zeros(n, dtype=np.uint32))
+                self._collect_bufs[(det_cap, n)] = buf
+            dets, per = buf
+            n_out = C.c_size_t(0)
+            st = self.lib.batch_collect(self.h, ticket, capi.ptr(dets), det_cap, capi.ptr(per), C.byref(n_out))
+            if st == capi.ERR_CAPACITY and attempt == 0 and n_out.value > det_cap:
+                # device-tail batches stay pending when the array was too small (include/vofod.h): come back with the
+                # size the library asked for.  (A batch that went through the host tail is consumed: the retry then
+                # reports NOT_PENDING and the capacity error is raised.)
+                msg = self.lib.last_error_string(self.h)
+                det_cap = int(n_out.value)
+                continue
+            if st == capi.ERR_NOT_PENDING and attempt == 1:
+                raise VofodError(capi.ERR_CAPACITY, "vofod_batch_collect", f"more than det_cap detections ({msg.decode() if msg else ''})")
+            self._check(st, "vofod_batch_collect")
+            return dets[: n_out.value].copy(), per.copy()
 
     def raycast_begin(self, scan: ScanData, tf: np.ndarray, allow: Sequence[int] = ()):
         tfa = np.ascontiguousarray(tf, dtype=np.float32).reshape(12)
