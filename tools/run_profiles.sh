@@ -16,4 +16,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1 || exit 1
 # and the pipelined default, for the record of how the kernels overlap (tools/timeline.py reads it)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pipelined -- python3 $R/bench.py --steps 12 --warmup 2 --cpu-baseline-scans 0 --no-profile-pass > $OUT/pipelined.log 2>&1 || exit 1
-cd $R && python3 tools/summarize_profiles.py $OUT $TAG && python3 tools/timeline.py $OUT/pipelined 60 > profiles/${TAG}_timeline_pipelined.txt
+cd $R && python3 tools/summarize_profiles.py $OUT $TAG && python3 tools/timeline.py $OUT/pipelined > profiles/${TAG}_timeline_pipelined.txt
