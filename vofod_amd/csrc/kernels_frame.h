@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), hoff2);
       pt.w = __uint_as_float(static_cast<uint32_t>(*cntp++));  // points in the voxel (the record list below adds what a byte cannot hold)
       va.pts[rank] = pt;
-      va.bb[rank] = i;
+      reinterpret_cast<uint16_t*>(va.bb)[rank] = static_cast<uint16_t>(i);  // (node < LB_MAX: 16 bits; the general kernels keep 32-bit brick codes here)
       if (!write_tables)
         va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
       if (first)
@@ -1859,7 +1859,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     for (int u = 0; u < VU; u++)
     {
       const uint32_t v = v0 + u * FR_THREADS;
-      nodev[u] = v < V ? va.bb[v] : 0xffffffffu;
+      nodev[u] = v < V ? reinterpret_cast<const uint16_t*>(va.bb)[v] : 0xffffu;
     }
 #pragma unroll
     for (int u = 0; u < VU; u++)
