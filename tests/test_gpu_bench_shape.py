@@ -2,6 +2,8 @@
 oracle on the very frames bench.py generates, and every BASELINE.json configuration gets an oracle comparison at
 its full size.  Bit-exact on voxel indices / weights / labels / cluster tables; stated tolerances on OBB-derived
 floats, confidences and on the float-atomic raycast accumulation (as in test_gpu_parity.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -135,7 +137,8 @@ def test_large_batch_falls_back_per_batch_when_a_frame_overflows_lds(oracle, hip
         _compare_batches(ref, dev, sc, tf, clusters_cap=65536)
         names = _profiled_kernels(lib, dev)
         lib.profile_enable(dev.h, 0)
-        if batch == 1:
+        lds_off = os.environ.get("VOFOD_CCL") == "voxel" or (os.environ.get("VOFOD_FRAME_LDS") == "0" and os.environ.get("VOFOD_BRICK_LDS") == "0")
+        if batch == 1 and not lds_off:  # (tools/run_fallback_matrix.sh switches the LDS kernels off altogether)
             assert any(n.startswith(("k_brick_ccl_lds", "k_frame_lds")) for n in names), names  # no permanent latch
 
 

@@ -5,6 +5,7 @@ and map contents after integer/byte-exact stages; stated tolerances on OBB-deriv
 and on everything downstream of the float-atomic raycast accumulation.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -468,6 +469,8 @@ def test_pipelined_batches_equal_synchronous(oracle, hip):
 def test_collect_with_too_small_an_array_keeps_the_ticket(oracle, hip):
     """vofod_batch_collect with an `out` too small: VOFOD_ERR_CAPACITY, *n_out = the size needed, the ticket stays pending and
     the second call returns what the synchronous call returns (ids included: none were handed out by the failing call)"""
+    if os.environ.get("VOFOD_DEVICE_TAIL") == "0":
+        pytest.skip("host tail (tools/run_fallback_matrix.sh): the failing collect consumes the batch, as include/vofod.h says")
     ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=4)
     scene = synth.make_scene(21, n_targets=3)
     ap = synth.apriori_points(scene, 0.5)
