@@ -524,6 +524,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __builtin_amdgcn_s_setprio(FR_WAVE_PRIO);
   const uint32_t FRAME = blockIdx.x;
   FrameHdr& h = hdrs[FRAME];
+  if (rl.on)
+  {
+    // single-pass input: the frame's lattice (voxel_grid_weighted.cpp:61-113) is set up here, from the bounding box k_key1
+    // left in the header - one kernel less between the streaming kernel and this one (k_grid, a launch gap of the pipeline)
+    if (threadIdx.x == 0)
+      grid_of_frame(g, h);
+    __syncthreads();
+  }
   // single-pass input (k_key1): the list holds reference cells, the fragile points wait beside it with their coordinates
   const uint32_t n_ref = sa.counts[2 * FRAME];
   const uint32_t n_frag = rl.on ? sa.counts[2 * FRAME + 1] : 0u;

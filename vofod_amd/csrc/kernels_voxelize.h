@@ -241,11 +241,8 @@ __global__ __launch_bounds__(256) void k_bbox(const FrameArgs* args, const GridP
 }
 
 // voxel_grid_weighted.cpp:61-113: overflow guard, min_b/max_b, offset (+ alignment), div_b.
-__global__ void k_grid(const GridParams g, FrameHdr* hdrs)
+__device__ inline void grid_of_frame(const GridParams& g, FrameHdr& h)
 {
-  if (threadIdx.x != 0)
-    return;
-  FrameHdr& h = hdrs[blockIdx.x];
   if (h.n_in == 0)
     return;
   float min_p[3], max_p[3];
@@ -296,6 +293,12 @@ __global__ void k_grid(const GridParams g, FrameHdr* hdrs)
     h.n_in = 0;
     h.n_cells = h.n_words = 0;
   }
+}
+
+__global__ void k_grid(const GridParams g, FrameHdr* hdrs)
+{
+  if (threadIdx.x == 0)
+    grid_of_frame(g, hdrs[blockIdx.x]);
 }
 
 // Segmented reduction over runs of consecutive lanes holding the same key `w` (LiDAR points arrive in ring

@@ -1012,7 +1012,8 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   }
   else
     KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
-  KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
+  if (!(frame_plan && ws.ref_lattice.on))  // (k_frame_lds sets the lattice up itself behind k_key1)
+    KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
   if (two_phase)
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
   // Batches whose clustering will run inside LDS (plan_lds_ccl): brick-first frame kernel (kernels_frame.h).  One pass over
