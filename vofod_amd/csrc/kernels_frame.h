@@ -188,19 +188,23 @@ struct RefLattice
   int32_t on;
 };
 
+#ifndef KEY1_THREADS_DEF
+#define KEY1_THREADS_DEF 256
+#endif
+constexpr int KEY1_THREADS = KEY1_THREADS_DEF;  // threads per workgroup of k_key1
 #ifndef KEY1_PPT_DEF
 #define KEY1_PPT_DEF 8
 #endif
 constexpr int KEY1_PPT = KEY1_PPT_DEF;  // consecutive points per thread of k_key1 (a multiple of 4)
 template <bool PACKED>
-__global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
+__global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
   (void)GX;
   const FrameArgs a = args[FRAME];  // (a copy: the transform stays in scalar registers)
-  const uint32_t base_blk = BX * KEY2_THREADS * KEY1_PPT;
+  const uint32_t base_blk = BX * KEY1_THREADS * KEY1_PPT;
   if (base_blk >= a.n)
     return;
   const uint32_t i0 = base_blk + threadIdx.x * KEY1_PPT;
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
     mn[c] = wave_min(n_surv ? f2ord(fmn[c]) : 0x7fffffff);
     mx[c] = wave_max(n_surv ? f2ord(fmx[c]) : static_cast<int>(0x80000000u));
   }
-  __shared__ int s_red[KEY2_THREADS / 64][7];
-  __shared__ uint32_t s_wsum[KEY2_THREADS / 64], s_fsum[KEY2_THREADS / 64];
+  __shared__ int s_red[KEY1_THREADS / 64][7];
+  __shared__ uint32_t s_wsum[KEY1_THREADS / 64], s_fsum[KEY1_THREADS / 64];
   __shared__ uint32_t s_base, s_fbase;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t incl = wave_incl_scan(cnt);
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
   __syncthreads();
   uint32_t off = incl - cnt, total = 0, foff = fincl - fcnt, ftotal = 0;
 #pragma unroll
-  for (int w = 0; w < KEY2_THREADS / 64; w++)
+  for (int w = 0; w < KEY1_THREADS / 64; w++)
   {
     const uint32_t x = s_wsum[w], y = s_fsum[w];
     off += w < wave ? x : 0u;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key1(const FrameArgs* __restri
     s_base = static_cast<uint32_t>(both);
     s_fbase = static_cast<uint32_t>(both >> 32);
     uint32_t tot = 0;
-    for (int w = 0; w < KEY2_THREADS / 64; w++)
+    for (int w = 0; w < KEY1_THREADS / 64; w++)
     {
       tot += static_cast<uint32_t>(s_red[w][0]);
       for (int c = 0; c < 3; c++)
@@ -1122,7 +1126,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), hoff1);
       pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), hoff2);
       pt.w = __uint_as_float(static_cast<uint32_t>(*cntp++));  // points in the voxel (the record list below adds what a byte cannot hold)
-      va.pts[rank] = pt;
+      va.pts[rank] = pt;  // (through L2 on purpose: it merges the scattered 16-byte records into lines; non-temporal stores cost 21 % of the throughput)
       reinterpret_cast<uint16_t*>(va.bb)[rank] = static_cast<uint16_t>(i);  // (node < LB_MAX: 16 bits; the general kernels keep 32-bit brick codes here)
       if (!write_tables)
         va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);

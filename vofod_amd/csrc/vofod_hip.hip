@@ -1003,12 +1003,12 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   if (frame_plan && ws.ref_lattice.on)
   {
     // one pass over the input: bounding box + reference cells (k_key1), then the frames' lattices
-    // (k_init_hdr has cleared the frames' list counters; one workgroup per KEY2_THREADS * KEY1_PPT points, no stride loop)
-    const uint32_t gk1 = std::max(1u, (max_pts + KEY2_THREADS * KEY1_PPT - 1) / (KEY2_THREADS * KEY1_PPT));
+    // (k_init_hdr has cleared the frames' list counters; one workgroup per KEY1_THREADS * KEY1_PPT points, no stride loop)
+    const uint32_t gk1 = std::max(1u, (max_pts + KEY1_THREADS * KEY1_PPT - 1) / (KEY1_THREADS * KEY1_PPT));
     if (packed)
-      KLAUNCH(h, k_key1<true>, fgrid(g, gk1), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
+      KLAUNCH(h, k_key1<true>, fgrid(g, gk1), dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
     else
-      KLAUNCH(h, k_key1<false>, fgrid(g, gk1), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
+      KLAUNCH(h, k_key1<false>, fgrid(g, gk1), dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
   }
   else
     KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
