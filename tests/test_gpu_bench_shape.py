@@ -137,7 +137,7 @@ def test_large_batch_falls_back_per_batch_when_a_frame_overflows_lds(oracle, hip
         _compare_batches(ref, dev, sc, tf, clusters_cap=65536)
         names = _profiled_kernels(lib, dev)
         lib.profile_enable(dev.h, 0)
-        lds_off = os.environ.get("VOFOD_CCL") == "voxel" or (os.environ.get("VOFOD_FRAME_LDS") == "0" and os.environ.get("VOFOD_BRICK_LDS") == "0")
+        lds_off = os.environ.get("VOFOD_CCL") == "voxel" or os.environ.get("VOFOD_BRICK_LDS") == "0"  # (no LDS clustering: no frame kernel either)
         if batch == 1 and not lds_off:  # (tools/run_fallback_matrix.sh switches the LDS kernels off altogether)
             assert any(n.startswith(("k_brick_ccl_lds", "k_frame_lds")) for n in names), names  # no permanent latch
 
