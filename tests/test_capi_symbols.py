@@ -53,3 +53,23 @@ def test_library_loader_fails_loudly_when_missing(monkeypatch, tmp_path):
     monkeypatch.setattr(vofod_amd, "LIB_PATH", tmp_path / "libvofod_hip.so")
     with pytest.raises(ImportError):
         vofod_amd.library()
+
+
+def test_bench_byte_model_names_the_kernels_of_the_batched_path():
+    """bench.py prices the path kernels by name: a kernel of the batched fast path that is launched by the driver but missing
+    from the algorithmic-bytes table would silently drop out of the roofline (k_key1 once did)"""
+    import re
+
+    root = ROOT
+    bench = (root / "bench.py").read_text()
+    table = bench[bench.index("alg = {"):bench.index("for nm, k in kernels.items():")]
+    priced = set(re.findall(r'"(k_[a-z0-9_]+)', table))
+    driver = (root / "vofod_amd" / "csrc" / "vofod_hip.hip").read_text()
+    launched = set(re.findall(r"KLAUNCH(?:_LDS)?\(h, (?:vk::)?(k_[a-z0-9_]+)", driver))
+    streaming = {k for k in launched if k in ("k_key1", "k_key2", "k_bbox", "k_frame_lds")}
+    assert streaming == {"k_key1", "k_key2", "k_bbox", "k_frame_lds"}
+    assert streaming <= priced, streaming - priced
+    prefixes = bench[bench.index("path_prefixes = ("):]
+    prefixes = prefixes[: prefixes.index(")")]
+    for k in streaming:
+        assert any(k.startswith(p) for p in re.findall(r'"(k_[a-z0-9_]+)"', prefixes)), k
