@@ -133,6 +133,7 @@ def main():
         n_det = 0
         inflight = []
         host_prof = os.environ.get("VOFOD_BENCH_HOSTPROF") == "1"  # diagnostics: where the host thread spends a step
+        step_log = [] if os.environ.get("VOFOD_BENCH_STEPLOG") == "1" else None  # diagnostics: completion time of every step
         t_sub = t_col = 0.0
         for _ in range(k):
             ta = time.perf_counter()
@@ -144,12 +145,17 @@ def main():
                 n_det += len(dets)
             t_sub += tb - ta
             t_col += time.perf_counter() - tb
+            if step_log is not None:
+                step_log.append((time.perf_counter(), tb - ta))
         if host_prof and k > 1:
             print(f"[host] per step: submit {1e6 * t_sub / k:.0f} us, collect (incl. waiting) {1e6 * t_col / k:.0f} us", file=sys.stderr)
         while inflight:
             dets, per = det.batch_collect(inflight.pop(0))
             publish(dets, per)
             n_det += len(dets)
+        if step_log:
+            d = np.diff(np.array([t for t, _ in step_log])) * 1e3
+            print(f"[steps] k={k} ms between step completions (ms inside submit): " + " ".join(f"{x:.2f}({1e3 * sb:.2f})" for x, (_, sb) in zip(d, step_log[1:])), file=sys.stderr)
         return n_det
 
     def sync():
@@ -157,6 +163,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("VOFOD_BENCH_GC") == "off":  # diagnostics
+        import gc
+
+        gc.collect()
+        gc.freeze()
+        gc.disable()
     if args.warmup:
         run_steps(args.warmup)
     sync()

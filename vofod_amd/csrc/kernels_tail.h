@@ -275,14 +275,28 @@ __global__ __launch_bounds__(TP_THREADS) void k_tail_prep(const GridParams g, co
   }
 }
 
-// one wave per frame: the floating clusters (extractDetections :843-846) in cluster order
-__global__ __launch_bounds__(64) void k_tail_finish(const TailCluster* __restrict__ tailc, const vc::ExploreResult* __restrict__ results, FrameDets* __restrict__ dets)
+// one wave per frame: the floating clusters (extractDetections :843-846) in cluster order.  The frame's record is written
+// twice: to the workspace (device memory, read by the capacity fall-back) and straight into the caller-visible pinned host
+// slot `hout` (135 KB per 256 frames over PCIe).  No copy command follows the tail: a D2H hipMemcpyAsync queued behind kernels
+// occupies an SDMA engine while it waits, the runtime then brings up a further engine for the next batch's copy, and each
+// first use of an engine blocked vofod_batch_submit for 6-7 ms (three times within the first twenty batches of a process).
+__global__ __launch_bounds__(64) void k_tail_finish(const TailCluster* __restrict__ tailc, const vc::ExploreResult* __restrict__ results, FrameDets* __restrict__ dets, FrameDets* __restrict__ hout)
 {
   const uint32_t f = blockIdx.x;
   const int lane = threadIdx.x;
   FrameDets& out = dets[f];
-  if (out.fallback)
+  const uint32_t fb_in = out.fallback;
+  if (fb_in)
+  {
+    if (hout && lane == 0)
+    {
+      hout[f].n = 0;
+      hout[f].fallback = fb_in;
+      hout[f].status = out.status;
+      hout[f].n_jobs = out.n_jobs;
+    }
     return;
+  }
   const TailCluster tc = tailc[f * TP_MAXC + lane];
   bool det = false, bad = false;
   double conf = 0.0;
@@ -308,15 +322,26 @@ __global__ __launch_bounds__(64) void k_tail_finish(const TailCluster* __restric
       d.pad = 0;
       d.conf_sum = conf;
       out.d[pos] = d;
+      if (hout)
+        hout[f].d[pos] = d;
     }
   }
   if (lane == 0)
   {
-    out.n = n;
+    uint32_t fb = 0;
     if (n > TP_MAXD)
-      out.fallback |= TAIL_FB_DETS;
+      fb |= TAIL_FB_DETS;
     if (bm)
-      out.fallback |= TAIL_FB_EXPLORE;
+      fb |= TAIL_FB_EXPLORE;
+    out.n = n;
+    out.fallback = fb;
+    if (hout)
+    {
+      hout[f].n = n;
+      hout[f].fallback = fb;
+      hout[f].status = out.status;
+      hout[f].n_jobs = out.n_jobs;
+    }
   }
 }
 

@@ -170,9 +170,36 @@ inline float ulp32(float x)
 
 }  // namespace
 
+// VOFOD_CALLTRACE=1 (diagnostics): every HIP call of the driver that keeps the host longer than 0.3 ms is reported
+struct SlowCall
+{
+  const char* what;
+  int line;
+  std::chrono::steady_clock::time_point t0;
+  static bool on()
+  {
+    static const bool v = std::getenv("VOFOD_CALLTRACE") != nullptr;
+    return v;
+  }
+  SlowCall(const char* w, int l) : what(w), line(l)
+  {
+    if (on())
+      t0 = std::chrono::steady_clock::now();
+  }
+  ~SlowCall()
+  {
+    if (!on())
+      return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 0.3)
+      std::fprintf(stderr, "[vofod calltrace] %.2f ms in %s (line %d)\n", ms, what, line);
+  }
+};
+
 #define HIPCHK(expr)                                                                                         \
   do                                                                                                         \
   {                                                                                                          \
+    SlowCall sc_(#expr, __LINE__);                                                                           \
     const hipError_t e_ = (expr);                                                                            \
     if (e_ != hipSuccess)                                                                                    \
     {                                                                                                        \
@@ -218,7 +245,10 @@ struct Prof
       (h)->prof.recs.push_back(r_);                                          \
     }                                                                        \
     else                                                                     \
+    {                                                                        \
+      SlowCall sc_(#kern, __LINE__);                                         \
       hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+    }                                                                        \
   } while (0)
 
 // (the same with dynamic LDS)
@@ -266,6 +296,7 @@ struct Workspace
   vtd::TailCluster* d_tailc = nullptr;
   vtd::FrameDets* d_dets = nullptr;
   vtd::FrameDets* h_dets = nullptr;  // pinned
+  vtd::FrameDets* h_dets_dev = nullptr;  // the same slots as the device sees them (k_tail_finish writes the records there)
   uint32_t* d_job_be = nullptr;      // [2][F]: first and one-past-last explore job of every frame
   // per-frame launch arguments in pinned host memory: their upload is a true asynchronous copy, so a batch is enqueued while the
   // previous chain still runs (a copy from pageable memory makes the submitting thread wait for the stream)
@@ -402,7 +433,10 @@ struct Workspace
       return e;
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_lite), sizeof(PackedLite) * F)) != hipSuccess)
       return e;
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_dets), sizeof(vtd::FrameDets) * F)) != hipSuccess)
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_dets), sizeof(vtd::FrameDets) * F, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+      return e;
+    std::memset(h_dets, 0, sizeof(vtd::FrameDets) * F);
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h_dets_dev), h_dets, 0)) != hipSuccess)
       return e;
     if ((e = h_args.assign(F, FrameArgs{})) != hipSuccess)
       return e;
@@ -1855,11 +1889,9 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
             ws.d_dets);
     KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched, eb.d_ovl_list,
             eb.d_ovl_count, eb.d_results, eb.d_visited);
-    KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets);
+    // the records (135 KB) go straight into the pinned host slots from k_tail_finish: no copy command on any stream (see there)
+    KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets, ws.h_dets_dev);
     HIPCHK(hipEventRecord(h->ev_explore, h->stream));
-    // the records come back on the tail stream itself (135 KB): a copy stream per workspace would share a hardware queue
-    // with one of the pipeline's streams, and a copy waiting there for its tail holds up the kernels queued behind it
-    HIPCHK(hipMemcpyAsync(ws.h_dets, ws.d_dets, sizeof(vtd::FrameDets) * n, hipMemcpyDeviceToHost, h->stream));
     tail_stream_used = h->stream;
   }
   else if (ws.lite)
