@@ -7,6 +7,9 @@ pre-warmed voxel map, inputs already resident in HBM.  With N GPUs every rank pr
 step (weak scaling, no data-path collective; `--scaling strong` splits F frames over the ranks instead) and
 the fixed-size detection records are all-gathered with RCCL at the end of each step.  Prints ONE JSON line
 on rank 0.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (one process per GPU, rendezvous on 127.0.0.1)
+before anything touches the GPU; under `python -m torch.distributed.run` the launcher's RANK / WORLD_SIZE are used.
 """
 from __future__ import annotations
 
@@ -29,14 +32,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400, help="a step lasts ~0.6 ms: 400 steps keep the timed region long enough to be stable")
-    ap.add_argument("--warmup", type=int, default=20, help="untimed steps (the clocks ramp up during the first ones)")
+    ap.add_argument("--steps", type=int, default=200, help="a step lasts ~0.5 ms")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps (first-use work of the runtime: queues, code objects)")
     ap.add_argument("--frames", type=int, default=256, help="independent scans per GPU per step (one workgroup per frame clusters in LDS: 256 frames fill the 256 CUs)")
     ap.add_argument("--voxel-size", type=float, default=0.25)
     ap.add_argument("--sensor", default="os1-128")
     ap.add_argument("--map-warm-scans", type=int, default=96)
     ap.add_argument("--cpu-baseline-scans", type=int, default=512, help="scans timed through the CPU oracle (0 disables); ~10 s of single-thread CPU work")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--host-input-steps", type=int, default=12, help="steps of the host-resident input leg (pinned host columns, VOFOD_MEM_HOST: the nodelet's operating point); 0 disables")
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight (1..4); their kernel chains run on streams of their own and overlap on the device")
     ap.add_argument("--collective", choices=("torch", "cabi"), default="torch", help="N > 1: all-gather through torch.distributed (RCCL / gloo) or through the product's C-ABI (vofod_allgather_detections: RCCL from libvofod_hip.so)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
@@ -59,8 +63,57 @@ def build_detector(lib, sensor, voxel_size, frames, device):
     return VoFOD(lib, sp, dp)
 
 
+def launch_ranks(n: int) -> int:
+    """`bench.py --gpus N` run as a plain script: start the N ranks as child processes of this one (which never initialises
+    the GPU) with the torch.distributed environment of a one-node job; rank 0 prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # a rank failed: the others would wait in the rendezvous / a collective for ever
+                    q.terminate()
+    return rc
+
+
+def stub_rank(args):
+    """VOFOD_BENCH_STUB=1 (tests/test_bench_launch.py, CPU): the launch and rendezvous logic of the N>1 path without the
+    GPU workload - every rank joins a gloo group, the ranks' ids are all-gathered, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"stub": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks_seen": [int(t.item()) for t in seen], "local_rank": int(os.environ["LOCAL_RANK"])}))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))  # (before any GPU initialisation: the children own the devices)
+    if os.environ.get("VOFOD_BENCH_STUB") == "1":
+        return stub_rank(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,10 +162,16 @@ def main():
     from vofod_amd import dist as vdist
 
     # all-gather payload: D_MAX 128-byte detection records + the count per frame, RCCL over xGMI
-    rec_local = torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
-    rec_all = torch.zeros((world, F, vdist.FRAME_F64), dtype=torch.float64, device=cdev)
-    rec_hosts = [torch.zeros((F, vdist.FRAME_F64), dtype=torch.float64).pin_memory() for _ in range(2)]  # the async copy of one step is not overwritten by the next
-    pub_count = [0]
+    def gather_bufs(n_frames):
+        return {
+            "local": torch.zeros((n_frames, vdist.FRAME_F64), dtype=torch.float64, device=cdev),
+            "all": torch.zeros((world, n_frames, vdist.FRAME_F64), dtype=torch.float64, device=cdev),
+            # (two pinned slots: the async copy of one step is not overwritten by the next)
+            "hosts": [torch.zeros((n_frames, vdist.FRAME_F64), dtype=torch.float64).pin_memory() for _ in range(2)] if world > 1 else [],
+            "count": 0,
+        }
+
+    gb = {"cur": gather_bufs(F)}
     cabi_comm = None
     if world > 1 and args.collective == "cabi":
         cabi_comm = vdist.CabiComm(lib, rank, world, local_rank, bootstrap=vdist.torch_bootstrap(cdev))
@@ -121,13 +180,14 @@ def main():
         if cabi_comm is not None:
             cabi_comm.allgather(dets, per)
         elif world > 1:
-            rec_host = rec_hosts[pub_count[0] & 1]
-            pub_count[0] += 1
+            b = gb["cur"]
+            rec_host = b["hosts"][b["count"] & 1]
+            b["count"] += 1
             vdist.pack_detections(dets, per, out=rec_host.numpy())
-            rec_local.copy_(rec_host, non_blocking=True)
-            vdist.allgather_detections(rec_local, rec_all)
+            b["local"].copy_(rec_host, non_blocking=True)
+            vdist.allgather_detections(b["local"], b["all"])
 
-    def run_steps(k):
+    def run_steps(k, scans=scans, tfs=tfs):
         """k batches through the submit/collect pipeline: batch i+1 is enqueued before batch i is collected, so the host
         tail of one batch overlaps the device chain of the next.  Every batch is submitted and collected inside the call."""
         n_det = 0
@@ -181,6 +241,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # configs[3] as written: 256 scans per step in total, split over the ranks (strong scaling), all-gather included.  On one
+    # GPU this is the headline run itself; on N GPUs every rank takes the first 256 / N of its frames.
+    strong = None
+    if world > 1 and args.scaling == "weak":
+        Fs = max(4, min(F, 256 // world))
+        s_scans, s_tfs = scans[:Fs], tfs[:Fs]
+        gb["cur"] = gather_bufs(Fs)
+        run_steps(max(args.warmup, 3), s_scans, s_tfs)
+        sync()
+        t1 = time.perf_counter()
+        run_steps(args.steps, s_scans, s_tfs)
+        sync()
+        dts = time.perf_counter() - t1
+        t = torch.tensor([dts], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dts = float(t.item())
+        strong = {"frames_total_per_step": world * Fs, "frames_per_gpu_per_step": Fs, "frames_per_s": world * Fs * args.steps / dts, "ms_per_step": 1e3 * dts / args.steps,
+                  "note": "configs[3]: 256 scans per step split over the GPUs (strong scaling), detections all-gathered every step"}
+
     out = None
     if rank == 0:
         frames = world * F * args.steps
@@ -211,6 +290,11 @@ def main():
                 "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight on streams of their own; classification tail on the device",
             },
         }
+        if strong is not None:
+            out["config3_strong"] = strong
+        elif world == 1 and F == 256 and args.scaling == "weak":
+            out["config3_strong"] = {"frames_total_per_step": F, "frames_per_gpu_per_step": F, "frames_per_s": frames / dt, "ms_per_step": 1e3 * dt / args.steps,
+                                     "note": "configs[3] on one GPU is the headline run itself (256 scans per step)"}
         # single-stream (stateful, sequential) latency of the same scan shape
         seq = synth.scan_sequence(scene, args.sensor, 6, seed0=5000)
         seq_dev = []
@@ -227,7 +311,7 @@ def main():
         single_ms = 1e3 * (time.perf_counter() - t1) / (len(seq) - 1)
         out["single_stream"] = {"ms_per_scan": single_ms, "frames_per_s": 1e3 / single_ms, "note": "sequential vofod_process_scan with map update, device-resident input"}
 
-        if F > 32:
+        if F > 32 and world == 1:
             # configs[3] spreads 256 scans over 8 GPUs: 32 per GPU and step.  The same handle, batches of 32 frames.
             sub, sub_tfs = scans[:32], tfs[:32]
 
@@ -248,6 +332,8 @@ def main():
             dt32 = time.perf_counter() - t1
             out["config3_share"] = {"frames_per_gpu_per_step": 32, "frames_per_s": 32 * 100 / dt32, "ms_per_step": 1e3 * dt32 / 100,
                                     "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU; one workgroup per frame leaves 7/8 of the CUs idle in k_frame_lds"}
+        if world == 1 and args.host_input_steps > 0:
+            out["host_input"] = host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w)
         if not args.no_profile_pass:
             out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F)
             # the same bytes over the pipelined step time of this rank (kernels of consecutive batches overlap: the step is
@@ -265,6 +351,47 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w):
+    """The drop-in's real operating point: the nodelet hands over a host-resident cloud (vofod_nodelet.cpp:882,
+    INTEGRATION.md passes VOFOD_MEM_HOST).  The batch's packed x|y|z columns sit in ONE pinned host block; the library
+    moves them with one 2-D copy per batch on its streaming stage's stream, so the copy of batch k+1 overlaps the frame
+    kernel and the tail of batch k.  PCIe-inclusive rate - reported beside `value`, never as `value`."""
+    F = len(host_scans)
+    n_pts = h * w
+    hcols = torch.empty((F, 3, n_pts), dtype=torch.float32).pin_memory()
+    for f, s in enumerate(host_scans):
+        hcols[f, 0] = torch.from_numpy(s.x)
+        hcols[f, 1] = torch.from_numpy(s.y)
+        hcols[f, 2] = torch.from_numpy(s.z)
+    hs = [ScanData(x=hcols[f, 0].data_ptr(), y=hcols[f, 1].data_ptr(), z=hcols[f, 2].data_ptr(), width=w, height=h, stride_bytes=4, memspace=capi.MEM_HOST) for f in range(F)]
+
+    def run(k):
+        infl = []
+        for _ in range(k):
+            infl.append(det.batch_submit(hs, tfs))
+            if len(infl) == args.inflight:
+                det.batch_collect(infl.pop(0))
+        while infl:
+            det.batch_collect(infl.pop(0))
+
+    run(3)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run(args.host_input_steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    nbytes = 12.0 * n_pts * F
+    return {
+        "frames_per_s": F * args.host_input_steps / dt,
+        "ms_per_step": 1e3 * dt / args.host_input_steps,
+        "steps": args.host_input_steps,
+        "h2d_bytes_per_step": nbytes,
+        "h2d_GBps": nbytes * args.host_input_steps / dt / 1e9,
+        "note": "pinned host x|y|z columns (12 B/point), VOFOD_MEM_HOST, one hipMemcpy2DAsync per batch overlapped with the previous batch's chain; bound by the host link "
+        "(PCIe Gen5 x16: 64 GB/s raw, ~50-55 GB/s achievable = ~33-36 k frames/s of 1.57 MB); the 48-byte ouster AoS of the nodelet would move 4x the bytes",
+    }
 
 
 def profile_pass(lib, det, scans, tfs, n_pts, V, F):
@@ -389,7 +516,18 @@ def cpu_baseline(args, gpu_det, host_scans):
         s = host_scans[i % len(host_scans)]
         det.process_scan(s.scan, s.tf, flags=capi.SCAN_NO_MAP_UPDATE)
     dt = time.perf_counter() - t0
+    # per-stage host wall clock of the same oracle under the reference's ScopeTimer checkpoint names
+    # (vofod_nodelet.cpp:929-964), mean over a small sample (the debug call also copies the clouds out)
+    names = ["filtering", "clusterization", "close X far", "vmap update", "classification"]
+    acc = np.zeros(len(names))
+    ns = min(16, len(host_scans))
+    for i in range(ns):
+        _, dbg = det.process_scan(host_scans[i].scan, host_scans[i].tf, flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+        acc += np.array(dbg["stage_ms"][: len(names)])
+    stage_ms = {nm: float(v / ns) for nm, v in zip(names, acc)}
     return {
+        "stage_ms": stage_ms,
+        "stage_ms_note": f"mean over {ns} scans, mrs_lib::ScopeTimer checkpoint names of processMsg (vofod_nodelet.cpp:929-964); read-only map: 'vmap update' is empty",
         "value": n / dt,
         "unit": "frames/s",
         "cores": 1,

@@ -63,6 +63,13 @@ inline Api& api()
   return a;
 }
 
+// one mutex for loading the library and for the process-wide error string
+inline std::mutex& load_mutex()
+{
+  static std::mutex m;
+  return m;
+}
+
 }  // namespace vcoll
 
 struct vofod_comm
@@ -83,8 +90,7 @@ int vofod_comm_unique_id(uint8_t id[VOFOD_COMM_ID_BYTES])
   if (!id)
     return VOFOD_ERR_INVALID_ARG;
   static_assert(VOFOD_COMM_ID_BYTES == sizeof(vcoll::UniqueId), "ncclUniqueId is 128 bytes");
-  static std::mutex m;
-  std::scoped_lock lck(m);
+  std::scoped_lock lck(vcoll::load_mutex());
   if (!vcoll::api().load())
     return VOFOD_ERR_DEVICE;
   vcoll::UniqueId u;
@@ -99,19 +105,34 @@ int vofod_comm_create(const uint8_t id[VOFOD_COMM_ID_BYTES], int32_t rank, int32
   if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks)
     return VOFOD_ERR_INVALID_ARG;
   *out = nullptr;
-  if (!vcoll::api().load())
-    return VOFOD_ERR_DEVICE;
+  {
+    std::scoped_lock lck(vcoll::load_mutex());
+    if (!vcoll::api().load())
+      return VOFOD_ERR_DEVICE;
+  }
   if (hipSetDevice(device) != hipSuccess)
+  {
+    std::scoped_lock lck(vcoll::load_mutex());
+    vcoll::api().err = "hipSetDevice failed";
     return VOFOD_ERR_DEVICE;
+  }
   auto* c = new vofod_comm;
   c->rank = rank;
   c->n_ranks = n_ranks;
   c->device = device;
   vcoll::UniqueId u;
   std::memcpy(u.internal, id, sizeof(u.internal));
-  if (vcoll::api().CommInitRank(&c->comm, n_ranks, u, rank) != 0 || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+  const bool comm_ok = vcoll::api().CommInitRank(&c->comm, n_ranks, u, rank) == 0;
+  if (!comm_ok)
+    c->comm = nullptr;
+  if (!comm_ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
   {
-    delete c;
+    {
+      std::scoped_lock lck(vcoll::load_mutex());
+      vcoll::api().err = comm_ok ? "hipStreamCreate failed" : "ncclCommInitRank failed";
+    }
+    c->stream = nullptr;
+    vofod_comm_destroy(c);  // releases the communicator when only the stream failed
     return VOFOD_ERR_DEVICE;
   }
   *out = c;
@@ -140,8 +161,12 @@ const char* vofod_comm_last_error(vofod_comm* c) { return c ? c->err.c_str() : v
 
 int vofod_allgather_detections(vofod_comm* c, const vofod_detection* local, const uint32_t* n_per_frame, size_t frames_per_rank, size_t d_max, vofod_detection* all, uint32_t* all_counts)
 {
-  if (!c || !n_per_frame || !all || !all_counts || d_max == 0 || (frames_per_rank && !local && false))
+  if (!c || !n_per_frame || !all || !all_counts || d_max == 0)
     return VOFOD_ERR_INVALID_ARG;
+  if (!local)  // allowed only when this rank has no detection at all
+    for (size_t f = 0; f < frames_per_rank; f++)
+      if (n_per_frame[f])
+        return VOFOD_ERR_INVALID_ARG;
   std::scoped_lock lck(c->mtx);
   if (hipSetDevice(c->device) != hipSuccess)
     return VOFOD_ERR_DEVICE;

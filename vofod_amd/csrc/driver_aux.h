@@ -687,6 +687,9 @@ void vofod_destroy(vofod_handle* h)
     (void)hipHostFree(h->h_bgcount);
   if (h->sep.h_small)
     (void)hipHostFree(h->sep.h_small);
+  for (hipEvent_t e : {h->ev_stagger, h->ev_explore, h->ev_bgcount})
+    if (e)
+      (void)hipEventDestroy(e);
   if (h->stream)
     (void)hipStreamDestroy(h->stream);
   if (h->stream_tail)

@@ -327,6 +327,7 @@ struct Workspace
   bool finalize_fused = false;  // ... and the cluster table / candidate list too
   bool closefar_fused = false;  // launch_cluster answered hasCloseTo as well (dilated image inside k_flatten)
   bool bitmap_clean = false;   // the occupancy bitmaps are all-zero (k_finalize clears the words it used)
+  vofod_dyn_params job_dp{};   // the dynamic parameters the pending batch was submitted with
   bool rerun = false;          // the next launch repeats this workspace's batch (LDS overflow): frame arguments and staged columns are kept
   void* d_members_big = nullptr;  // vox_cap gathered candidate members: read-back of a frame whose list exceeds the packed slot
   // state of a submitted, not yet collected batch (vofod_batch_submit / vofod_batch_collect)
@@ -1188,6 +1189,9 @@ int cluster_tables(vofod_handle* h, const GridParams& g, float tol, float cmax, 
   {
     ct = &h->ctab[h->ctab_next];
     h->ctab_next ^= 1;
+    // the slot's device tables are rewritten in place below: kernels of batches in flight (non-blocking streams) may still
+    // read them.  A new tolerance is a rare event; the device is simply drained first.
+    HIPCHK(hipDeviceSynchronize());
     ct->valid = false;
     ct->lds_ok = false;
     std::vector<StencilRow> rows;
@@ -1491,9 +1495,8 @@ int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
 
 // Fallback of k_explore for one frame: the same flood fills and sums on read-back boxes of the map.
 int host_explore_frame(vofod_handle* h, std::vector<HostCluster>& cl, const vt::MemberIndex& by_root, const std::vector<int>& job_of,
-                       const std::vector<vc::ExploreJob>& jobs, std::vector<vc::ExploreResult>& results, bool no_update, float thr_frontiers, float thr_new)
+                       const std::vector<vc::ExploreJob>& jobs, std::vector<vc::ExploreResult>& results, bool no_update, float thr_frontiers, float thr_new, const vofod_dyn_params& dp)
 {
-  const vofod_dyn_params& dp = h->dp;
   std::vector<uint64_t> pending;  // voxels this scan's classification turned into frontiers (:1712-1715)
   auto unlin = [&](uint64_t li, int i3[3]) {
     i3[0] = static_cast<int>(li % h->hg.s[0]);
@@ -1605,7 +1608,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
                    uint32_t* n_out_per_frame, size_t* n_out, vofod_scan_debug* dbg)
 {
   const vofod_static_params& sp = h->sp;
-  const vofod_dyn_params& dp = h->dp;
+  // A submitted batch is classified with the dynamic parameters of its submission: vofod_set_dynamic_params may be called
+  // between submit and collect (DetectionParams.cfg semantics: "between any two calls"), and the collect half (position sigma,
+  // min_points, the host fall-back tail) as well as the re-run of an overflowed batch must not mix the two parameter sets.
+  if (phase == FRAMES_LAUNCH && !ws.rerun)
+    ws.job_dp = h->dp;
+  const vofod_dyn_params& dp = (phase == FRAMES_SYNC) ? h->dp : ws.job_dp;
   if (phase == FRAMES_COLLECT)
   {
     n = ws.job_n;
@@ -1634,6 +1642,14 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
         return VOFOD_ERR_SIZE_MISMATCH;
     }
   const bool no_update = flags & VOFOD_SCAN_NO_MAP_UPDATE;
+  // re-run of the batch that overflowed the LDS kernels: the flag is consumed here, whatever path this call takes (an early
+  // error return must not leave it standing for a different batch), and only a launch of the very same job reuses its inputs
+  bool rerun = false;
+  if (phase != FRAMES_COLLECT)
+  {
+    rerun = ws.rerun && ws.job_n == n;
+    ws.rerun = false;
+  }
   int ret = VOFOD_OK;
   auto t0 = clk::now();
   static const bool trace = std::getenv("VOFOD_TRACE") != nullptr;
@@ -1717,14 +1733,44 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // ---- stage inputs, K1-K6 (filterAndTransform :621-684)
   // (the re-run of a batch that overflowed the LDS kernels keeps the frame arguments and the staged columns of its first
   // launch: the caller's host buffers need not outlive vofod_batch_submit)
-  for (uint32_t f = 0; f < n && !ws.rerun; f++)
+  // Host-resident batches whose frames are packed x | y | z columns at a constant pitch (one pcl / numpy block per batch, or
+  // per-frame blocks of one arena) cross PCIe with ONE 2-D copy command instead of three per frame: at 256 frames the 768
+  // copy calls alone cost more host time than the whole device chain.  The copy is enqueued on the streaming stage's stream:
+  // it overlaps the frame kernel and the tail of the batches in front.  (Pinned memory makes it asynchronous; a pageable
+  // source is staged by the runtime and blocks the call.)
+  bool staged_2d = false;
+  if (!rerun && n >= 2 && scans[0].memspace == VOFOD_MEM_HOST)
+  {
+    const char* x0 = static_cast<const char*>(scans[0].x);
+    const ptrdiff_t pitch = static_cast<const char*>(scans[1].x) - x0;
+    bool ok = pitch >= static_cast<ptrdiff_t>(npts * 12);
+    for (uint32_t f = 0; f < n && ok; f++)
+    {
+      const vofod_scan& s = scans[f];
+      const char* xf = x0 + static_cast<ptrdiff_t>(f) * pitch;
+      ok = s.memspace == VOFOD_MEM_HOST && s.stride_bytes == 4 && static_cast<const char*>(s.x) == xf && static_cast<const char*>(s.y) == xf + npts * 4 &&
+           static_cast<const char*>(s.z) == xf + npts * 8;
+    }
+    if (ok && ws.pt_cap == npts)
+    {
+      HIPCHK(hipMemcpy2DAsync(ws.d_stage, sizeof(float) * 5 * ws.pt_cap, x0, static_cast<size_t>(pitch), npts * 12, n, hipMemcpyHostToDevice, h->stream));
+      for (uint32_t f = 0; f < n; f++)
+      {
+        float* base = ws.d_stage + static_cast<size_t>(f) * ws.pt_cap * 5;
+        const int r = stage_cloud(h, ws, f, base, base + ws.pt_cap, base + 2 * static_cast<size_t>(ws.pt_cap), nullptr, nullptr, 4, npts, VOFOD_MEM_DEVICE, FA_SCAN, tfs + 12 * f);
+        if (r != VOFOD_OK)
+          return r;
+      }
+      staged_2d = true;
+    }
+  }
+  for (uint32_t f = 0; f < n && !rerun && !staged_2d; f++)
   {
     const vofod_scan& s = scans[f];
     const int r = stage_cloud(h, ws, f, s.x, s.y, s.z, nullptr, nullptr, s.stride_bytes, npts, s.memspace, FA_SCAN, tfs + 12 * f);
     if (r != VOFOD_OK)
       return r;
   }
-  ws.rerun = false;
   const float leaf[3] = {sp.voxel_size, sp.voxel_size, sp.voxel_size};
   const int zero[3] = {0, 0, 0};
   float align_center[3];
@@ -1950,6 +1996,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       // update the map); the caller runs it again on the global-memory kernels
       h->lds_ccl_off = true;
       ws.rerun = true;
+      ws.job_n = n;
       ws.bitmap_clean = false;
       return CCL_RETRY_STATUS;
     }
@@ -2297,7 +2344,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     if (any_host && job_begin[f + 1] > job_begin[f])
     {
       // fallback (Manhattan radius or job count beyond the device kernel's limits): sequential host path over read-back boxes
-      r = host_explore_frame(h, T.cl, T.by_root, T.job_of, jobs, results, no_update, thr_frontiers, thr_new);
+      r = host_explore_frame(h, T.cl, T.by_root, T.job_of, jobs, results, no_update, thr_frontiers, thr_new, dp);
       if (r != VOFOD_OK)
         return r;
     }
