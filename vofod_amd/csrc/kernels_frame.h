@@ -196,9 +196,62 @@ constexpr int KEY1_THREADS = KEY1_THREADS_DEF;  // threads per workgroup of k_ke
 #define KEY1_PPT_DEF 8
 #endif
 constexpr int KEY1_PPT = KEY1_PPT_DEF;  // consecutive points per thread of k_key1 (a multiple of 4)
+// v_min3_f32 / v_max3_f32: two new points per instruction.  A quiet NaN operand is ignored (the other operands decide), which
+// makes qNaN the neutral element of both: dropped points are replaced by it once and need no second select.
+__device__ __forceinline__ float min3_raw(float a, float b, float c)
+{
+  float d;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c)
+{
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// max(|a|, |b|, |c|) in one instruction (source modifiers)
+__device__ __forceinline__ float max3_abs(float a, float b, float c)
+{
+  float d;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// wave-wide float min / max, every step one VALU instruction with a DPP source (lanes without a source keep their value)
+__device__ __forceinline__ float wave_fmin(float v)
+{
+  asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_fmax(float v)
+{
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Round 3: the kernel was bound by its vector instructions (~112 executed per point).  Now: the transform and the cell
+// expression work on PAIRS of consecutive points as packed-f32 operations (v_pk_mul_f32 / v_pk_add_f32: every lane of a
+// packed instruction rounds like the scalar one, so the separately rounded se3 association is kept); the bounding box is
+// two v_min3 / v_max3 per axis and pair with qNaN standing in for dropped points; a point is "solid" when
+// max(|fr - 0.5|) over the axes stays below 0.5 - eps (one v_max3 with |.| modifiers instead of three interval tests).
 template <bool PACKED>
 __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
 {
+#pragma clang fp contract(off)
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
@@ -209,13 +262,19 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
     return;
   const uint32_t i0 = base_blk + threadIdx.x * KEY1_PPT;
   float px[KEY1_PPT], py[KEY1_PPT], pz[KEY1_PPT];
-  if (PACKED && i0 + KEY1_PPT <= a.n)
+  if constexpr (PACKED)
   {
-    const char *cx = a.x + static_cast<uint64_t>(i0) * 4, *cy = a.y + static_cast<uint64_t>(i0) * 4, *cz = a.z + static_cast<uint64_t>(i0) * 4;
+    // packed float columns, 16-byte aligned, the number of points a multiple of 4 (the host checks): whole 16-byte loads
+    // only, no strided path in this instantiation (its 64-bit address arithmetic costs registers the packed path never uses)
 #pragma unroll
     for (int q = 0; q < KEY1_PPT / 4; q++)
     {
-      const float4 x0 = ldg_f4(cx + 16 * q), y0 = ldg_f4(cy + 16 * q), z0 = ldg_f4(cz + 16 * q);
+      float4 x0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), y0 = x0, z0 = x0;  // (0,0,0) lies inside the exclude box; the index test drops it anyway
+      if (i0 + 4 * q < a.n)
+      {
+        const uint64_t o = (static_cast<uint64_t>(i0) + 4 * q) * 4;
+        x0 = ldg_f4(a.x + o), y0 = ldg_f4(a.y + o), z0 = ldg_f4(a.z + o);
+      }
       px[4 * q] = x0.x, px[4 * q + 1] = x0.y, px[4 * q + 2] = x0.z, px[4 * q + 3] = x0.w;
       py[4 * q] = y0.x, py[4 * q + 1] = y0.y, py[4 * q + 2] = y0.z, py[4 * q + 3] = y0.w;
       pz[4 * q] = z0.x, pz[4 * q + 1] = z0.y, pz[4 * q + 2] = z0.z, pz[4 * q + 3] = z0.w;
@@ -233,70 +292,91 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
       pz[j] = ok ? ldf(a.z, a.stride, i) : 0.0f;
     }
   }
-  // (float minima / maxima per thread, ordered integers from the wave reduction on: the kernel is bound by its vector
-  // instructions, and v_min_f32 on a select is three instructions fewer per axis than the ordered-integer form.  The
-  // sign of a zero bound may differ from the ordered form's; floor(min * inv) - all that is made of it - does not.)
   float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
   uint32_t code[KEY1_PPT];
-  uint32_t cnt = 0, n_surv = 0, frag_mask = 0;
+  uint32_t cnt = 0, frag_mask = 0;
   uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their indices in the cloud
-  // Branch-free per point (the kernel was bound by the scalar unit's exec-mask bookkeeping, not by its float work): a value
-  // lies inside a closed interval iff the median of (value, low, high) is the value itself - one v_med3 + one compare per
-  // axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed point, which fails the
-  // operation-area test: the explicit isfinite() of the first crop is implied.
+  // Branch-free per point: a value lies inside a closed interval iff the median of (value, low, high) is the value itself -
+  // one v_med3 + one compare per axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed
+  // point, which fails the operation-area test: the explicit isfinite() of the first crop is implied.
   auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
-  // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop instead of being
-  // copied there in front of every test)
+  // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop)
   float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
-  float eps_hi = 1.0f - rl.eps;
 #pragma unroll
   for (int c = 0; c < 3; c++)
     asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
-  asm volatile("" : "+v"(eps_hi));
-  const uint32_t dlast[3] = {static_cast<uint32_t>(rl.dims[0] - 1), static_cast<uint32_t>(rl.dims[1] - 1), static_cast<uint32_t>(rl.dims[2] - 1)};
+  const float solid_lim = 0.5f - rl.eps;
+  const float qnan = __int_as_float(0x7fc00000);
 #pragma unroll
-  for (int j = 0; j < KEY1_PPT; j++)
+  for (int jp = 0; jp < KEY1_PPT / 2; jp++)
   {
-    const float p0 = px[j], p1 = py[j], p2 = pz[j];
-    const bool in_ex = static_cast<int>(inside(p0, g.ex_min[0], ex_hi[0])) & inside(p1, g.ex_min[1], ex_hi[1]) & inside(p2, g.ex_min[2], ex_hi[2]);
-    float q[3];
+    const int j0 = 2 * jp, j1 = 2 * jp + 1;
+    const f32x2 X = {px[j0], px[j1]}, Y = {py[j0], py[j1]}, Z = {pz[j0], pz[j1]};
+    bool in_ex[2], in_op[2], keep[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+      in_ex[e] = static_cast<int>(inside(X[e], g.ex_min[0], ex_hi[0])) & inside(Y[e], g.ex_min[1], ex_hi[1]) & inside(Z[e], g.ex_min[2], ex_hi[2]);
+    f32x2 q[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
-      q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
-    const bool in_op = static_cast<int>(inside(q[0], g.op_min[0], op_hi[0])) & inside(q[1], g.op_min[1], op_hi[1]) & inside(q[2], g.op_min[2], op_hi[2]);
-    const bool keep = (i0 + j < a.n) & !in_ex & in_op;
-    code[j] = FR_CODE_NONE;
-    if (!__any(keep))
-      continue;  // (wave-uniform) 64 dropped points: whole rings look at the sky
-    bool solid = keep;  // survivor whose reference cell is certain
-    uint32_t kk[3];
+    {
+      const f32x2 c0 = {a.tf[4 * r + 0], a.tf[4 * r + 0]}, c1 = {a.tf[4 * r + 1], a.tf[4 * r + 1]}, c2 = {a.tf[4 * r + 2], a.tf[4 * r + 2]}, c3 = {a.tf[4 * r + 3], a.tf[4 * r + 3]};
+      q[r] = c0 * X + (c1 * Y + (c2 * Z + c3));
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+    {
+      in_op[e] = static_cast<int>(inside(q[0][e], g.op_min[0], op_hi[0])) & inside(q[1][e], g.op_min[1], op_hi[1]) & inside(q[2][e], g.op_min[2], op_hi[2]);
+      keep[e] = (i0 + j0 + e < a.n) & !in_ex[e] & in_op[e];
+    }
+    code[j0] = code[j1] = FR_CODE_NONE;
+    if (!__any(keep[0] | keep[1]))
+      continue;  // (wave-uniform) 128 dropped points: whole rings look at the sky
+    // pcl::getMinMax3D (voxel_grid_weighted.cpp:58) over the kept points
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
-      // pcl::getMinMax3D (voxel_grid_weighted.cpp:58), as compare + select (fminf would add a canonicalising copy per operand)
-      fmn[c] = (static_cast<int>(keep) & (q[c] < fmn[c])) ? q[c] : fmn[c];
-      fmx[c] = (static_cast<int>(keep) & (q[c] > fmx[c])) ? q[c] : fmx[c];
-      const float t = __fmul_rn(__fsub_rn(q[c], rl.off[c]), g.inv[c]);
-      const float fl = floorf(t);
-      const float fr = __fsub_rn(t, fl);  // exact
-      kk[c] = static_cast<uint32_t>(static_cast<int>(fl));  // (negative or huge: above every lattice size)
-      solid = solid & inside(fr, rl.eps, eps_hi) & (kk[c] <= dlast[c]);
+      const float m0 = keep[0] ? q[c][0] : qnan, m1 = keep[1] ? q[c][1] : qnan;
+      fmn[c] = min3_raw(fmn[c], m0, m1);
+      fmx[c] = max3_raw(fmx[c], m0, m1);
     }
-    n_surv += keep ? 1u : 0u;
-    cnt += solid ? 1u : 0u;
-    code[j] = solid ? (kk[0] | (kk[1] << 11) | (kk[2] << 22)) : FR_CODE_NONE;
-    frag_mask |= (keep & !solid) ? (1u << j) : 0u;  // kept aside by its index: k_frame_lds fetches the point again and encodes it exactly
+    // reference cell (voxel_grid_weighted.cpp:131-136 with the reference offset) and the distance from the cell's middle
+    f32x2 fl[3], gmid[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+      const f32x2 off = {rl.off[c], rl.off[c]}, inv = {g.inv[c], g.inv[c]};
+      const f32x2 t = (q[c] - off) * inv;
+      fl[c][0] = floorf(t[0]);
+      fl[c][1] = floorf(t[1]);
+      const f32x2 half = {0.5f, 0.5f};
+      gmid[c] = t - (fl[c] + half);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+    {
+      const uint32_t k0 = static_cast<uint32_t>(static_cast<int>(fl[0][e])), k1 = static_cast<uint32_t>(static_cast<int>(fl[1][e])), k2 = static_cast<uint32_t>(static_cast<int>(fl[2][e]));
+      // (negative or huge cells set bits above the fields: one test for all three; a kept point lies inside the operation
+      // area, whose cells the reference lattice covers - the test only guards the packing)
+      const bool fits = (k0 | k1 | (k2 << 1)) < 2048u;
+      const bool solid = keep[e] & fits & (max3_abs(gmid[0][e], gmid[1][e], gmid[2][e]) <= solid_lim);
+      cnt += solid ? 1u : 0u;
+      code[j0 + e] = solid ? (k0 | (k1 << 11) | (k2 << 22)) : FR_CODE_NONE;
+      frag_mask |= (keep[e] & !solid) ? (1u << (j0 + e)) : 0u;  // kept aside by its index: k_frame_lds fetches the point again and encodes it exactly
+    }
   }
-  // bounding box and survivor count of the block (as k_bbox) ...
-  const uint32_t ns = wave_sum(n_surv);
+  // bounding box of the block ...
+  const bool any_kept = (cnt | frag_mask) != 0u;
   int mn[3], mx[3];
 #pragma unroll
   for (int c = 0; c < 3; c++)
   {
-    mn[c] = wave_min(n_surv ? f2ord(fmn[c]) : 0x7fffffff);
-    mx[c] = wave_max(n_surv ? f2ord(fmx[c]) : static_cast<int>(0x80000000u));
+    // (+-inf where the wave kept nothing: the ordered form of +inf / -inf is the identity of the integer atomics below)
+    mn[c] = f2ord(wave_fmin(fmn[c]));
+    mx[c] = f2ord(wave_fmax(fmx[c]));
   }
-  __shared__ int s_red[KEY1_THREADS / 64][7];
+  (void)any_kept;
+  __shared__ int s_red[KEY1_THREADS / 64][6];
   __shared__ uint32_t s_wsum[KEY1_THREADS / 64], s_fsum[KEY1_THREADS / 64];
   __shared__ uint32_t s_base, s_fbase;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -309,11 +389,10 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
   }
   if (lane == 0)
   {
-    s_red[wave][0] = static_cast<int>(ns);
     for (int c = 0; c < 3; c++)
     {
-      s_red[wave][1 + c] = mn[c];
-      s_red[wave][4 + c] = mx[c];
+      s_red[wave][c] = mn[c];
+      s_red[wave][3 + c] = mx[c];
     }
   }
   __syncthreads();
@@ -334,20 +413,16 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
         (total | ftotal) ? atomicAdd(reinterpret_cast<unsigned long long*>(&sa.counts[2 * FRAME]), static_cast<unsigned long long>(total) | (static_cast<unsigned long long>(ftotal) << 32)) : 0ull;
     s_base = static_cast<uint32_t>(both);
     s_fbase = static_cast<uint32_t>(both >> 32);
-    uint32_t tot = 0;
-    for (int w = 0; w < KEY1_THREADS / 64; w++)
+    if (total | ftotal)
     {
-      tot += static_cast<uint32_t>(s_red[w][0]);
-      for (int c = 0; c < 3; c++)
-      {
-        mn[c] = min(mn[c], s_red[w][1 + c]);
-        mx[c] = max(mx[c], s_red[w][4 + c]);
-      }
-    }
-    if (tot)
-    {
+      for (int w = 0; w < KEY1_THREADS / 64; w++)
+        for (int c = 0; c < 3; c++)
+        {
+          mn[c] = min(mn[c], s_red[w][c]);
+          mx[c] = max(mx[c], s_red[w][3 + c]);
+        }
       FrameHdr& h = hdrs[FRAME];
-      atomicAdd(&h.n_in, tot);
+      atomicAdd(&h.n_in, total + ftotal);
 #pragma unroll
       for (int c = 0; c < 3; c++)
       {

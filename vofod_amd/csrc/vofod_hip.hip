@@ -489,9 +489,11 @@ struct vofod_handle
   hipStream_t stream_tail = nullptr;  // tail (k_explore) of collected async batches
   hipStream_t stream_key = nullptr;   // staged pipeline: streaming kernels of all submitted batches, lowest priority
   hipStream_t stream_frame = nullptr; // staged pipeline: frame kernels of all submitted batches
+  // Batches in flight (more than the four hardware queues the runtime maps streams onto gain nothing: eight 32-frame batches
+  // in flight measured 121 k frames/s against 132 k with three).  Slots are allocated on first use.
   static constexpr int MAX_INFLIGHT = 4;
-  hipStream_t chain_stream[MAX_INFLIGHT] = {nullptr, nullptr, nullptr, nullptr};  // [0] == stream; in-flight batches run their chains on separate streams and overlap on the device
-  Workspace wsx[MAX_INFLIGHT - 1];                                                  // workspaces of tickets 1..3 (ticket 0 uses ws)
+  hipStream_t chain_stream[MAX_INFLIGHT] = {};  // [0] == stream; in-flight batches run their chains on separate streams and overlap on the device
+  Workspace wsx[MAX_INFLIGHT - 1];              // workspaces of tickets 1..3 (ticket 0 uses ws)
   Workspace* slot(int t) { return t == 0 ? &ws : &wsx[t - 1]; }
 
   float exclude_center[3], oparea_center[3];
@@ -1033,7 +1035,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   for (uint32_t f = 0; f < n && packed; f++)
   {
     const FrameArgs& a = ws.h_args[f];
-    packed = a.stride == 4 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
+    packed = a.stride == 4 && (a.n & 3u) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
   }
   if (frame_plan && ws.ref_lattice.on)
   {
