@@ -5,8 +5,9 @@ from vofod_amd import capi, synth
 from vofod_amd.detector import VoFOD, default_params
 
 
-def make_pair(oracle, hip, sensor="os1-16", voxel_size=0.5, max_batch=1, **dyn):
-    """An oracle detector and a HIP detector with identical parameters."""
+def make_pair(oracle, hip, sensor="os1-16", voxel_size=0.5, max_batch=1, lut=None, mask=None, **dyn):
+    """An oracle detector and a HIP detector with identical parameters.  `lut` = (directions, offsets) and `mask` replace
+    the simulated sensor model (vofod_nodelet.cpp:358-372, 506-560) on both sides."""
     h, w, vfov_deg, _ = synth.SENSORS[sensor]
     dets = []
     for lib in (oracle, hip):
@@ -17,7 +18,7 @@ def make_pair(oracle, hip, sensor="os1-16", voxel_size=0.5, max_batch=1, **dyn):
         sp.max_batch_frames = max_batch
         for k, v in dyn.items():
             setattr(dp, k, v)
-        dets.append(VoFOD(lib, sp, dp))
+        dets.append(VoFOD(lib, sp, dp, lut_directions=None if lut is None else lut[0], lut_offsets=None if lut is None else lut[1], mask=mask))
     return dets
 
 

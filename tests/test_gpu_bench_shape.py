@@ -48,7 +48,7 @@ def _compare_batches(ref, dev, scans, tfs, chunk=32, clusters_cap=8192):
 
 def test_bench_workload_256_frames_os1_128(oracle, hip):
     """configs[3] on one GPU = the bench.py default: 256 x OS1-128 @ 0.25 m, the warmed map, vofod_batch_submit/collect
-    (k_key -> k_slab_emit / fused voxeliser -> k_brick_ccl_lds), every frame against the oracle"""
+    (k_key1 -> k_frame_lds -> device tail), every frame against the oracle"""
     F = 256
     ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=F)
     scene = synth.bench_scene()
@@ -73,6 +73,54 @@ def test_bench_workload_256_frames_os1_128(oracle, hip):
         assert len(got[0]) == len(want[0])
         np.testing.assert_array_equal(got[0]["n_points"], want[0]["n_points"])
         np.testing.assert_array_equal(got[0]["position"], want[0]["position"])
+
+def test_device_tail_at_the_bench_shape_with_many_targets(oracle, hip):
+    """The classification tail ON THE DEVICE (k_tail_prep / k_explore / k_tail_finish: the path bench.py times, debug output
+    off) at 256 x OS1-128 @ 0.25 m, compared field by field with the oracle's detections - on a scene whose twelve floating
+    targets appear after the map was warmed, so that the tail kernels carry dozens of candidate clusters per batch."""
+    F = 256
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=F)
+    warm_scene = synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=0)
+    scene = synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=12)  # same buildings (drawn first from the seed), new targets
+    np.testing.assert_array_equal(scene.boxes[: scene.n_static], warm_scene.boxes[: warm_scene.n_static])
+    synth.warm_map(dev, warm_scene, "os1-128", 24)
+    _hand_over_map(dev, ref)
+    st = dev.status()
+    assert st.background_pts_sufficient and st.sure_background_sufficient  # both latches: classify_cluster runs its flood fills
+    frames = synth.bench_frames(scene, "os1-128", F)
+    scans = [s.scan for s in frames]
+    tfs = np.stack([s.tf for s in frames])
+    want, want_per = [], []
+    for f0 in range(0, F, 32):  # the oracle, 32 frames at a time (no debug output: detections only)
+        d, per = ref.process_batch(scans[f0 : f0 + 32], tfs[f0 : f0 + 32])
+        d = d.copy()
+        d["frame"] += f0
+        want.append(d)
+        want_per.append(per)
+    want = np.concatenate(want)
+    want_per = np.concatenate(want_per)
+    assert len(want) >= 50, len(want)
+    want["id"] = np.arange(len(want), dtype=want["id"].dtype)  # ids run over the whole batch on the HIP side
+    lib = dev.lib
+    lib.profile_enable(dev.h, 1)
+    got, got_per = dev.process_batch(scans, tfs)  # synchronous, no debug: device tail
+    names = _profiled_kernels(lib, dev)
+    lib.profile_enable(dev.h, 0)
+    if os.environ.get("VOFOD_DEVICE_TAIL") != "0" and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK"):
+        assert "k_tail_prep" in names and "k_explore" in names and "k_tail_finish" in names, names
+    id0 = got["id"][0]
+    got = got.copy()
+    got["id"] -= id0
+    np.testing.assert_array_equal(got_per, want_per)
+    assert_detections_equal(want, got)
+    # the pipelined form (what bench.py times): three tickets in flight
+    tickets = [dev.batch_submit(scans, tfs) for _ in range(3)]
+    for t in tickets:
+        g, per = dev.batch_collect(t)
+        g = g.copy()
+        g["id"] -= g["id"][0]
+        np.testing.assert_array_equal(per, want_per)
+        assert_detections_equal(want, g)
 
 
 def _dense_scan(sensor, seed, extent, empty=False, zlo=-2.0, zhi=1.0):

@@ -387,6 +387,54 @@ def test_old_raycast_rule(oracle, hip):
         assert d.raycast_finish() == capi.OK
     np.testing.assert_allclose(dev.read_map(), ref.read_map(), rtol=1e-4, atol=1e-3)
 
+def test_real_ouster_lut_mask_and_min_intensity_through_raycast(oracle, hip):
+    """Row N1 through the GPU (vofod_nodelet.cpp:358-371, 506-560 feeding raycast_cloud :1441-1492): the LUT of a real
+    Ouster (non-zero lidar_origin_to_beam_origin_mm, a lidar -> sensor transform: non-zero beam offsets, `start = R lut.off + t`
+    :1477), a mask with ~20 % zeros laid out with pixel_shift_by_row (`!mask[idx] && range == 0` skips the ray :1449; a masked
+    pixel with a return is still cast), raycast/min_intensity > 0 (:1446) - sequence with raycast begin / finish against the oracle."""
+    from vofod_amd.detector import VoFOD, default_params, mask_layout, ouster_lut
+
+    sensor, vs = "os1-16", 0.5
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    rng = np.random.default_rng(2024)
+    altitude = np.linspace(vfov_deg / 2, -vfov_deg / 2, h)        # Ouster rows run top to bottom
+    azimuth = rng.uniform(-3.2, 3.2, h)                            # per-beam azimuth offsets of the calibration
+    tf = np.eye(4)
+    tf[:3, :3] = [[-1, 0, 0], [0, -1, 0], [0, 0, 1]]               # lidar_to_sensor_transform of an OS1 (metadata)
+    tf[:3, 3] = [0.0, 0.0, 36.18]
+    img = (rng.random((h, w)) < 0.8).astype(np.uint8) * 255        # ~20 % masked-out pixels
+    shift = np.array([12 if r % 2 else 4 for r in range(h)], dtype=np.int32) + np.arange(h, dtype=np.int32) % 3  # pixel_shift_by_row
+    dets = []
+    for lib in (oracle, hip):
+        dirs, offs = ouster_lut(lib, w, h, azimuth, altitude, origin_mm=15.806, tf=tf)
+        assert np.abs(offs).max() > 0.01                           # the beam offsets are really there (metres)
+        mask = mask_layout(lib, img, w, h, shift)
+        assert 0.1 < 1.0 - mask.astype(bool).mean() < 0.3
+        sp, dp = default_params(lib)
+        sp.voxel_size = vs
+        sp.sensor_hrays, sp.sensor_vrays = w, h
+        sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+        dp.raycast__min_intensity = 300.0                          # synthetic intensities are U(0, 1000): ~30 % of the rays are dropped
+        dets.append(VoFOD(lib, sp, dp, lut_directions=dirs, lut_offsets=offs, mask=mask))
+    ref, dev = dets
+    scene = synth.make_scene(21, n_targets=2)
+    scans = synth.scan_sequence(scene, sensor, 4, seed0=300)
+    n_zero_masked = sum(int(((s.range == 0) & (mask == 0)).sum()) for s in scans)
+    n_hit_masked = sum(int(((s.range > 0) & (mask == 0)).sum()) for s in scans)
+    assert n_zero_masked > 100 and n_hit_masked > 100              # both sides of the :1449 condition occur
+    for d in (ref, dev):
+        synth.seed_ground(d)
+    _run_sequence(ref, dev, scans)
+    # and the same LUT / mask against the default sensor model: the raycast map differs, i.e. the inputs were really used
+    plain_ref, plain_dev = make_pair(oracle, hip, sensor, vs)
+    for d in (plain_dev, dev):
+        d.reset()
+        synth.seed_ground(d)
+        d.process_scan(scans[0].scan, scans[0].tf)
+        assert d.raycast_begin(scans[0].scan, scans[0].tf) == capi.OK
+    a, b = plain_dev.read_map(capi.MAP_RAYCAST), dev.read_map(capi.MAP_RAYCAST)
+    assert float(a.sum(dtype=np.float64)) > 1.2 * float(b.sum(dtype=np.float64)) > 0  # fewer rays were cast (intensity gate, mask)
+
 
 def test_aos_ouster_layout_and_device_input(oracle, hip):
     """the 48-byte ouster_ros::Point AoS (x +0, y +4, z +8, intensity +16, range +36) through the strided-column view"""

@@ -54,7 +54,19 @@ def main():
                 dyn["voxel_map__thresholds__frontiers"] = float(rng.choice([-700.0, -500.0, -300.0]))
                 dyn["raycast__new_update_rule"] = int(rng.integers(0, 2))
                 desc += f" dyn {dyn}"
-            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch, **dyn)
+            lut = mask = None
+            if rng.integers(0, 2):  # a calibrated sensor instead of the simulated one: beam offsets, a mask, an intensity gate
+                from vofod_amd.detector import mask_layout, ouster_lut
+
+                hh, ww, vfov_deg, _ = synth.SENSORS[sensor]
+                tf4 = np.eye(4)
+                tf4[:3, :3] = [[-1, 0, 0], [0, -1, 0], [0, 0, 1]]
+                tf4[:3, 3] = [0.0, 0.0, float(rng.uniform(0.0, 50.0))]
+                lut = ouster_lut(hip, ww, hh, rng.uniform(-3.0, 3.0, hh), np.linspace(vfov_deg / 2, -vfov_deg / 2, hh), origin_mm=float(rng.uniform(0.0, 30.0)), tf=tf4)
+                mask = mask_layout(hip, (rng.random((hh, ww)) < rng.uniform(0.5, 1.0)).astype(np.uint8), ww, hh, rng.integers(0, 16, hh).astype(np.int32))
+                dyn["raycast__min_intensity"] = float(rng.choice([0.0, 100.0, 500.0]))
+                desc += f" calibrated lut+mask, min_intensity {dyn['raycast__min_intensity']}"
+            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch, lut=lut, mask=mask, **dyn)
             scene = synth.make_scene(int(rng.integers(0, 10_000)), n_targets=int(rng.integers(0, 4)))
             if use_apriori:
                 ap_pts = synth.apriori_points(scene, voxel)
@@ -109,6 +121,12 @@ def main():
             assert_scan_debug_equal(ha, hb)
             assert_detections_equal(ra, rb)
             np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+            # the raycast accumulation of that scan (LUT offsets, mask and intensity gate are inputs of this stage only)
+            sa = status_of(lambda: ref.raycast_begin(s.scan, s.tf))
+            sb = status_of(lambda: dev.raycast_begin(s.scan, s.tf))
+            assert sa == sb, f"raycast_begin status {sa} (oracle) vs {sb} (HIP)"
+            if sa == capi.OK:
+                np.testing.assert_allclose(dev.read_map(capi.MAP_RAYCAST), ref.read_map(capi.MAP_RAYCAST), rtol=2e-5, atol=2e-6)
         except Exception as e:  # noqa: BLE001
             print(f"MISMATCH at {desc}\n{type(e).__name__}: {str(e)[:1500]}", flush=True)
             return 1
