@@ -399,6 +399,544 @@ inline void jacobi_eigen3(const double A_in[3][3], double w[3], double V[3][3])
     w[i] = A[i][i];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// [3P] Eigen 3.3.7 `EigenSolver<Matrix3f>` restated (Eigen is not in /root/reference: package.xml pulls it through PCL;
+// version by distro inference, see the header).  pcl::MomentOfInertiaEstimation::computeEigenVectors
+// (moment_of_inertia_estimation.hpp) hands the float covariance to the GENERAL real solver, not to the self-adjoint one:
+//   EigenSolver::compute        -> RealSchur::compute (scale by max |a_ij|, HessenbergDecomposition, computeFromHessenberg:
+//                                  findSmallSubdiagEntry / splitOffTwoRows / computeShift / initFrancisQRStep /
+//                                  performFrancisQRStep), eigenvalues from the quasi-triangular T, doComputeEigenvectors
+//                                  (back substitution + multiplication by the Schur vectors)
+//   EigenSolver::eigenvectors   -> columns normalised; a complex pair gives (v_j + i v_j+1) and its conjugate,
+//                                  of which PCL keeps `.real()`.
+// All arithmetic in float, operation order as in the Eigen sources (dynamic-size blocks: plain left-to-right loops).
+// For a symmetric matrix the eigen-SPACES are those of any solver; inside a degenerate eigen-space (2 x 2 voxel squares,
+// cubes ...) the basis - and with it the OBB's extents - is decided by this algorithm's rounding path, which is why the
+// restatement follows it step by step.  It cannot be pinned against the real library here (parity unpinned).
+struct EigenSolver3f
+{
+  float T[3][3], U[3][3];
+  float re[3], im[3];
+  float vec_re[3][3];  // column j = real part of eigenvector j after EigenSolver::eigenvectors()
+  bool ok = true;
+
+  static void make_householder(const float* v, int size, float* ess, float& tau, float& beta)
+  {
+    float tail_sq = 0.0f;
+    for (int i = 1; i < size; i++)
+      tail_sq += v[i] * v[i];
+    const float c0 = v[0];
+    const float tol = std::numeric_limits<float>::min();
+    if (tail_sq <= tol)
+    {
+      tau = 0.0f;
+      beta = c0;
+      for (int i = 0; i < size - 1; i++)
+        ess[i] = 0.0f;
+    }
+    else
+    {
+      beta = std::sqrt(c0 * c0 + tail_sq);
+      if (c0 >= 0.0f)
+        beta = -beta;
+      for (int i = 0; i < size - 1; i++)
+        ess[i] = v[i + 1] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+  }
+  // M.block(r0, c0, nr, nc).applyHouseholderOnTheLeft(ess, tau)
+  static void house_left(float M[3][3], int r0, int c0, int nr, int nc, const float* ess, float tau)
+  {
+    if (nr == 1)
+    {
+      for (int c = 0; c < nc; c++)
+        M[r0][c0 + c] *= 1.0f - tau;
+      return;
+    }
+    if (tau == 0.0f)
+      return;
+    for (int c = 0; c < nc; c++)
+    {
+      float tmp = 0.0f;
+      for (int r = 1; r < nr; r++)
+        tmp += ess[r - 1] * M[r0 + r][c0 + c];
+      tmp += M[r0][c0 + c];
+      M[r0][c0 + c] -= tau * tmp;
+      for (int r = 1; r < nr; r++)
+        M[r0 + r][c0 + c] -= tau * ess[r - 1] * tmp;
+    }
+  }
+  static void house_right(float M[3][3], int r0, int c0, int nr, int nc, const float* ess, float tau)
+  {
+    if (nc == 1)
+    {
+      for (int r = 0; r < nr; r++)
+        M[r0 + r][c0] *= 1.0f - tau;
+      return;
+    }
+    if (tau == 0.0f)
+      return;
+    for (int r = 0; r < nr; r++)
+    {
+      float tmp = 0.0f;
+      for (int c = 1; c < nc; c++)
+        tmp += M[r0 + r][c0 + c] * ess[c - 1];
+      tmp += M[r0 + r][c0];
+      M[r0 + r][c0] -= tau * tmp;
+      for (int c = 1; c < nc; c++)
+        M[r0 + r][c0 + c] -= tau * tmp * ess[c - 1];
+    }
+  }
+  // JacobiRotation::makeGivens(p, q) (real case) and the two applications of splitOffTwoRows
+  static void make_givens(float p, float q, float& c, float& s)
+  {
+    if (q == 0.0f)
+    {
+      c = p < 0.0f ? -1.0f : 1.0f;
+      s = 0.0f;
+    }
+    else if (p == 0.0f)
+    {
+      c = 0.0f;
+      s = q < 0.0f ? 1.0f : -1.0f;
+    }
+    else if (std::fabs(p) > std::fabs(q))
+    {
+      const float t = q / p;
+      float u = std::sqrt(1.0f + t * t);
+      if (p < 0.0f)
+        u = -u;
+      c = 1.0f / u;
+      s = -t * c;
+    }
+    else
+    {
+      const float t = p / q;
+      float u = std::sqrt(1.0f + t * t);
+      if (q < 0.0f)
+        u = -u;
+      s = -1.0f / u;
+      c = -t * s;
+    }
+  }
+
+  void compute(const float A[3][3])
+  {
+    const int size = 3;
+    const float eps = std::numeric_limits<float>::epsilon();
+    const float consider_as_zero = std::numeric_limits<float>::min();
+    float scale = 0.0f;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        scale = std::max(scale, std::fabs(A[i][j]));
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+      {
+        T[i][j] = 0.0f;
+        U[i][j] = i == j ? 1.0f : 0.0f;
+      }
+    if (scale < consider_as_zero)
+    {
+      finish();
+      return;
+    }
+    // ---- HessenbergDecomposition::_compute on A / scale
+    float H[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        H[i][j] = A[i][j] / scale;
+    float hcoef[2] = {0.0f, 0.0f}, ess0 = 0.0f;
+    for (int i = 0; i < size - 1; i++)
+    {
+      const int rem = size - i - 1;
+      float v[2] = {H[i + 1][i], rem > 1 ? H[i + 2][i] : 0.0f}, ess[1] = {0.0f}, tau, beta;
+      make_householder(v, rem, ess, tau, beta);
+      H[i + 1][i] = beta;
+      if (rem > 1)
+        H[i + 2][i] = ess[0];  // (makeHouseholderInPlace keeps the essential part below the subdiagonal)
+      hcoef[i] = tau;
+      if (i == 0)
+        ess0 = ess[0];
+      house_left(H, i + 1, i + 1, rem, rem, ess, tau);
+      house_right(H, 0, i + 1, size, rem, ess, tau);
+    }
+    // matrixH: upper Hessenberg part; matrixQ = H_0 (H_1 acts on one row: tau = 0)
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        T[i][j] = (i <= j + 1) ? H[i][j] : 0.0f;
+    {
+      // HouseholderSequence(matA, hCoeffs).setLength(2).setShift(1) evaluated on the identity (evalTo: from the last vector
+      // up): Q = I - tau0 * u u^T with u = (0, 1, ess0)
+      const float u[3] = {0.0f, 1.0f, ess0};
+      (void)hcoef[1];
+      float Q[3][3];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+          Q[i][j] = i == j ? 1.0f : 0.0f;
+      // applyHouseholderOnTheLeft on the bottom-right 2 x 2 corner of the identity (rows 1..2, cols 1..2)
+      const float ess[1] = {u[2]};
+      house_left(Q, 1, 1, 2, 2, ess, hcoef[0]);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+          U[i][j] = Q[i][j];
+    }
+    // ---- RealSchur::computeFromHessenberg
+    const int max_iters = 40 * size;
+    int iu = size - 1, iter = 0, total_iter = 0;
+    float exshift = 0.0f;
+    float norm = 0.0f;
+    for (int j = 0; j < size; j++)
+      for (int i = 0; i < std::min(size, j + 2); i++)
+        norm += std::fabs(T[i][j]);
+    if (norm != 0.0f)
+    {
+      while (iu >= 0)
+      {
+        // findSmallSubdiagEntry
+        int il = iu;
+        while (il > 0)
+        {
+          float s = std::fabs(T[il - 1][il - 1]) + std::fabs(T[il][il]);
+          s = std::max(s * eps, consider_as_zero);
+          if (std::fabs(T[il][il - 1]) <= s)
+            break;
+          il--;
+        }
+        if (il == iu)  // one root found
+        {
+          T[iu][iu] = T[iu][iu] + exshift;
+          if (iu > 0)
+            T[iu][iu - 1] = 0.0f;
+          iu--;
+          iter = 0;
+        }
+        else if (il == iu - 1)  // two roots found: splitOffTwoRows
+        {
+          const float p = 0.5f * (T[iu - 1][iu - 1] - T[iu][iu]);
+          const float q = p * p + T[iu][iu - 1] * T[iu - 1][iu];
+          T[iu][iu] += exshift;
+          T[iu - 1][iu - 1] += exshift;
+          if (q >= 0.0f)
+          {
+            const float z = std::sqrt(std::fabs(q));
+            float c, s;
+            if (p >= 0.0f)
+              make_givens(p + z, T[iu][iu - 1], c, s);
+            else
+              make_givens(p - z, T[iu][iu - 1], c, s);
+            // m_matT.rightCols(size-iu+1).applyOnTheLeft(iu-1, iu, rot.adjoint()): x = row iu-1, y = row iu,
+            // (x, y) <- (c x - s y, s x + c y) for the adjoint of (c, s)  [apply_rotation_in_the_plane with (c, -s) conj]
+            for (int col = iu - 1; col < size; col++)
+            {
+              const float x = T[iu - 1][col], y = T[iu][col];
+              T[iu - 1][col] = c * x - s * y;
+              T[iu][col] = s * x + c * y;
+            }
+            // m_matT.topRows(iu+1).applyOnTheRight(iu-1, iu, rot): x = col iu-1, y = col iu, (x, y) <- (c x - s y, s x + c y)
+            for (int row = 0; row <= iu; row++)
+            {
+              const float x = T[row][iu - 1], y = T[row][iu];
+              T[row][iu - 1] = c * x - s * y;
+              T[row][iu] = s * x + c * y;
+            }
+            T[iu][iu - 1] = 0.0f;
+            for (int row = 0; row < size; row++)
+            {
+              const float x = U[row][iu - 1], y = U[row][iu];
+              U[row][iu - 1] = c * x - s * y;
+              U[row][iu] = s * x + c * y;
+            }
+          }
+          if (iu > 1)
+            T[iu - 1][iu - 2] = 0.0f;
+          iu -= 2;
+          iter = 0;
+        }
+        else  // no convergence yet (il == 0, iu == 2 for a 3 x 3)
+        {
+          float shift[3] = {T[iu][iu], T[iu - 1][iu - 1], T[iu][iu - 1] * T[iu - 1][iu]};
+          if (iter == 10)  // Wilkinson's original ad hoc shift
+          {
+            exshift += shift[0];
+            for (int i = 0; i <= iu; i++)
+              T[i][i] -= shift[0];
+            const float s = std::fabs(T[iu][iu - 1]) + std::fabs(T[iu - 1][iu - 2]);
+            shift[0] = 0.75f * s;
+            shift[1] = 0.75f * s;
+            shift[2] = -0.4375f * s * s;
+          }
+          if (iter == 30)  // MATLAB's new ad hoc shift
+          {
+            float s = (shift[1] - shift[0]) / 2.0f;
+            s = s * s + shift[2];
+            if (s > 0.0f)
+            {
+              s = std::sqrt(s);
+              if (shift[1] < shift[0])
+                s = -s;
+              s = s + (shift[1] - shift[0]) / 2.0f;
+              s = shift[0] - shift[2] / s;
+              exshift += s;
+              for (int i = 0; i <= iu; i++)
+                T[i][i] -= s;
+              shift[0] = shift[1] = shift[2] = 0.964f;
+            }
+          }
+          iter++;
+          total_iter++;
+          if (total_iter > max_iters)
+          {
+            ok = false;
+            break;
+          }
+          // initFrancisQRStep
+          int im;
+          float v[3] = {0.0f, 0.0f, 0.0f};
+          for (im = iu - 2; im >= il; --im)
+          {
+            const float Tmm = T[im][im];
+            const float r = shift[0] - Tmm;
+            const float s = shift[1] - Tmm;
+            v[0] = (r * s - shift[2]) / T[im + 1][im] + T[im][im + 1];
+            v[1] = T[im + 1][im + 1] - Tmm - r - s;
+            v[2] = T[im + 2][im + 1];
+            if (im == il)
+              break;
+            const float lhs = T[im][im - 1] * (std::fabs(v[1]) + std::fabs(v[2]));
+            const float rhs = v[0] * (std::fabs(T[im - 1][im - 1]) + std::fabs(Tmm) + std::fabs(T[im + 1][im + 1]));
+            if (std::fabs(lhs) < eps * rhs)
+              break;
+          }
+          // performFrancisQRStep
+          for (int k = im; k <= iu - 2; ++k)
+          {
+            const bool first = k == im;
+            float w[3];
+            if (first)
+              for (int i = 0; i < 3; i++)
+                w[i] = v[i];
+            else
+              for (int i = 0; i < 3; i++)
+                w[i] = T[k + i][k - 1];
+            float ess[2], tau, beta;
+            make_householder(w, 3, ess, tau, beta);
+            if (beta != 0.0f)
+            {
+              if (first && k > il)
+                T[k][k - 1] = -T[k][k - 1];
+              else if (!first)
+                T[k][k - 1] = beta;
+              house_left(T, k, k, 3, size - k, ess, tau);
+              house_right(T, 0, k, std::min(iu, k + 3) + 1, 3, ess, tau);
+              house_right(U, 0, k, size, 3, ess, tau);
+            }
+          }
+          {
+            float w[2] = {T[iu - 1][iu - 2], T[iu][iu - 2]}, ess[1], tau, beta;
+            make_householder(w, 2, ess, tau, beta);
+            if (beta != 0.0f)
+            {
+              T[iu - 1][iu - 2] = beta;
+              house_left(T, iu - 1, iu - 1, 2, size - iu + 1, ess, tau);
+              house_right(T, 0, iu - 1, iu + 1, 2, ess, tau);
+              house_right(U, 0, iu - 1, size, 2, ess, tau);
+            }
+          }
+          for (int i = im + 2; i <= iu; ++i)  // clean up pollution due to round-off errors
+          {
+            T[i][i - 2] = 0.0f;
+            if (i > im + 2)
+              T[i][i - 3] = 0.0f;
+          }
+        }
+      }
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        T[i][j] *= scale;
+    finish();
+  }
+
+  // EigenSolver::compute after the Schur form + doComputeEigenvectors + eigenvectors()
+  void finish()
+  {
+    const int size = 3;
+    const float eps = std::numeric_limits<float>::epsilon();
+    int i = 0;
+    while (i < size)
+    {
+      if (i == size - 1 || T[i + 1][i] == 0.0f)
+      {
+        re[i] = T[i][i];
+        im[i] = 0.0f;
+        ++i;
+      }
+      else
+      {
+        const float p = 0.5f * (T[i][i] - T[i + 1][i + 1]);
+        float t0 = T[i + 1][i], t1 = T[i][i + 1];
+        const float maxval = std::max(std::fabs(p), std::max(std::fabs(t0), std::fabs(t1)));
+        t0 /= maxval;
+        t1 /= maxval;
+        const float p0 = p / maxval;
+        const float z = maxval * std::sqrt(std::fabs(p0 * p0 + t0 * t1));
+        re[i] = re[i + 1] = T[i + 1][i + 1] + p;
+        im[i] = z;
+        im[i + 1] = -z;
+        i += 2;
+      }
+    }
+    float V[3][3];  // m_eivec
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+        V[r][c] = U[r][c];
+    float norm = 0.0f;
+    for (int j = 0; j < size; j++)
+      for (int c = std::max(j - 1, 0); c < size; c++)
+        norm += std::fabs(T[j][c]);
+    if (norm != 0.0f)
+    {
+      for (int n = size - 1; n >= 0; n--)
+      {
+        const float p = re[n], q = im[n];
+        if (q == 0.0f)  // scalar vector
+        {
+          float lastr = 0.0f, lastw = 0.0f;
+          int l = n;
+          T[n][n] = 1.0f;
+          for (int k = n - 1; k >= 0; k--)
+          {
+            const float w = T[k][k] - p;
+            float r = 0.0f;
+            for (int c = l; c <= n; c++)
+              r += T[k][c] * T[c][n];
+            if (im[k] < 0.0f)
+            {
+              lastw = w;
+              lastr = r;
+            }
+            else
+            {
+              l = k;
+              if (im[k] == 0.0f)
+              {
+                if (w != 0.0f)
+                  T[k][n] = -r / w;
+                else
+                  T[k][n] = -r / (eps * norm);
+              }
+              else  // solve real equations
+              {
+                const float x = T[k][k + 1], y = T[k + 1][k];
+                const float denom = (re[k] - p) * (re[k] - p) + im[k] * im[k];
+                const float t = (x * lastr - lastw * r) / denom;
+                T[k][n] = t;
+                if (std::fabs(x) > std::fabs(lastw))
+                  T[k + 1][n] = (-r - w * t) / x;
+                else
+                  T[k + 1][n] = (-lastr - y * t) / lastw;
+              }
+              const float t = std::fabs(T[k][n]);  // overflow control
+              if ((eps * t) * t > 1.0f)
+                for (int r2 = k; r2 < size; r2++)
+                  T[r2][n] /= t;
+            }
+          }
+        }
+        else if (q < 0.0f && n > 0)  // complex vector (columns n-1, n)
+        {
+          int l = n - 1;
+          if (std::fabs(T[n][n - 1]) > std::fabs(T[n - 1][n]))
+          {
+            T[n - 1][n - 1] = q / T[n][n - 1];
+            T[n - 1][n] = -(T[n][n] - p) / T[n][n - 1];
+          }
+          else
+          {
+            // (0, -T(n-1,n)) / (T(n-1,n-1) - p, q)
+            const float a = 0.0f, b = -T[n - 1][n], c = T[n - 1][n - 1] - p, d = q, den = c * c + d * d;
+            T[n - 1][n - 1] = (a * c + b * d) / den;
+            T[n - 1][n] = (b * c - a * d) / den;
+          }
+          T[n][n - 1] = 0.0f;
+          T[n][n] = 1.0f;
+          for (int k = n - 2; k >= 0; k--)
+          {
+            float ra = 0.0f, sa = 0.0f;
+            for (int c = l; c <= n; c++)
+            {
+              ra += T[k][c] * T[c][n - 1];
+              sa += T[k][c] * T[c][n];
+            }
+            const float w = T[k][k] - p;
+            if (im[k] < 0.0f)
+              continue;  // (a second complex pair cannot exist in a 3 x 3)
+            l = k;
+            if (im[k] == 0.0f)
+            {
+              const float a = -ra, b = -sa, c = w, d = q, den = c * c + d * d;
+              T[k][n - 1] = (a * c + b * d) / den;
+              T[k][n] = (b * c - a * d) / den;
+            }
+            const float t = std::max(std::fabs(T[k][n - 1]), std::fabs(T[k][n]));
+            if ((eps * t) * t > 1.0f)
+              for (int r2 = k; r2 < size; r2++)
+              {
+                T[r2][n - 1] /= t;
+                T[r2][n] /= t;
+              }
+          }
+          n--;
+        }
+      }
+      // back transformation: m_eivec.col(j) = m_eivec.leftCols(j+1) * m_matT.col(j).head(j+1)
+      for (int j = size - 1; j >= 0; j--)
+      {
+        float tmp[3];
+        for (int r = 0; r < 3; r++)
+        {
+          float acc = 0.0f;
+          for (int c = 0; c <= j; c++)
+            acc += V[r][c] * T[c][j];
+          tmp[r] = acc;
+        }
+        for (int r = 0; r < 3; r++)
+          V[r][j] = tmp[r];
+      }
+    }
+    // eigenvectors(): real columns normalised; a complex pair (j, j+1): (V_j + i V_j+1) / its norm and the conjugate
+    const float precision = 2.0f * eps;
+    for (int j = 0; j < size; j++)
+    {
+      const bool is_real = std::fabs(im[j]) <= std::fabs(re[j]) * precision || j + 1 == size;
+      if (is_real)
+      {
+        const float nn = std::sqrt(V[0][j] * V[0][j] + V[1][j] * V[1][j] + V[2][j] * V[2][j]);
+        for (int r = 0; r < 3; r++)
+          vec_re[r][j] = V[r][j] / nn;
+      }
+      else
+      {
+        float sq = 0.0f;
+        for (int r = 0; r < 3; r++)
+          sq += V[r][j] * V[r][j] + V[r][j + 1] * V[r][j + 1];
+        const float nn = std::sqrt(sq);
+        for (int r = 0; r < 3; r++)
+          vec_re[r][j] = vec_re[r][j + 1] = V[r][j] / nn;
+        ++j;
+      }
+    }
+  }
+};
+
+// which solver moie() uses: 0 = the EigenSolver restatement above (what PCL calls), 1 = cyclic Jacobi in double (the
+// independent cross-check of tests/test_oracle_kat.py).  Test hook: vofod_oracle_set_obb_solver.
+inline int& obb_solver()
+{
+  static int s = 0;
+  return s;
+}
+
 // moment_of_inertia_estimation.hpp: computeMeanValue, computeCovarianceMatrix (normalised by
 // point_mass_ = 1/n^2), computeEigenVectors (sort major >= middle >= minor, right-handed),
 // computeOBB (obb max initialised to FLT_MIN as PCL does, position = mean + R*shift).
@@ -444,7 +982,19 @@ inline Boxes moie(const std::vector<vofod_point_xyzr>& pts, const std::vector<in
       cov[r][cc] *= point_mass;
       A[r][cc] = cov[r][cc];
     }
-  jacobi_eigen3(A, w, V);
+  if (obb_solver() == 1)
+    jacobi_eigen3(A, w, V);
+  else
+  {
+    EigenSolver3f es;
+    es.compute(cov);
+    for (int k = 0; k < 3; k++)
+    {
+      w[k] = es.re[k];
+      for (int r = 0; r < 3; r++)
+        V[r][k] = es.vec_re[r][k];
+    }
+  }
   int major = 0, middle = 1, minor = 2;
   if (w[major] < w[middle])
     std::swap(major, middle);

@@ -1315,6 +1315,13 @@ int vofod_oracle_map_coord_to_idx(vofod_handle* h, float x, float y, float z, in
   return h->vmap.inLimitsIdx(c[0], c[1], c[2]);
 }
 
+// test hook: 0 = Eigen::EigenSolver restatement (default, what PCL calls), 1 = cyclic Jacobi in double (cross-check)
+int vofod_oracle_set_obb_solver(int solver)
+{
+  vo::obb_solver() = solver == 1 ? 1 : 0;
+  return VOFOD_OK;
+}
+
 int vofod_oracle_moie(const vofod_point_xyzr* pts, size_t n, float* aabb_min, float* aabb_max, float* obb_center, float* obb_size, float* eig)
 {
   std::vector<vofod_point_xyzr> v(pts, pts + n);

@@ -401,6 +401,109 @@ def test_moie_boxes(oracle):
     np.testing.assert_allclose(ctr, [0.25, 0.25, 0.0], atol=1e-6)
     assert size[0] == pytest.approx(math.hypot(math.sqrt(2.0), math.sqrt(0.5)), rel=1e-5)
 
+def _moie_call(oracle, pts_xyz, solver):
+    f = oracle.extra("vofod_oracle_moie", C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5)
+    setsolver = oracle.extra("vofod_oracle_set_obb_solver", C.c_int, [C.c_int])
+    setsolver(solver)
+    try:
+        pts = np.zeros(len(pts_xyz), dtype=capi.POINT_XYZR)
+        pts["x"], pts["y"], pts["z"] = pts_xyz[:, 0], pts_xyz[:, 1], pts_xyz[:, 2]
+        mn, mx, ctr, eig = (np.zeros(3, dtype=np.float32) for _ in range(4))
+        size = np.zeros(1, dtype=np.float32)
+        f(capi.ptr(pts), len(pts), capi.ptr(mn), capi.ptr(mx), capi.ptr(ctr), capi.ptr(size), capi.ptr(eig))
+        return ctr.copy(), float(size[0]), eig.copy()
+    finally:
+        setsolver(0)
+
+
+def _lattice(cells, vs=0.25, off=(12.375, -7.125, 3.625)):
+    return ((np.array(cells, dtype=np.float32) + np.float32(0.5)) * np.float32(vs) + np.array(off, dtype=np.float32)).astype(np.float32)
+
+
+def test_obb_solver_restatement_is_a_correct_eigen_solver(oracle):
+    """The restated Eigen::EigenSolver<Matrix3f> path (Hessenberg + shifted QR + back substitution, float) against numpy on
+    clusters with a simple spectrum: eigenvalues as numpy's eigh of the same n^2-normalised covariance (float tolerance)"""
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        p = rng.uniform(-3, 3, (int(rng.integers(4, 30)), 3)).astype(np.float32) * np.float32([1.0, 0.6, 0.3])
+        _, _, eig = _moie_call(oracle, p, 0)
+        c = (p - p.mean(0)).astype(np.float64)
+        want = np.sort(np.linalg.eigvalsh(c.T @ c / len(p) ** 2))[::-1]
+        np.testing.assert_allclose(eig, want, rtol=2e-4, atol=1e-6)
+
+
+def test_obb_solvers_agree_where_the_spectrum_is_simple(oracle):
+    """general small clusters (no repeated eigenvalue): the general solver PCL calls and an independent symmetric Jacobi solver
+    in double give the same OBB (centre, diagonal) within 1e-3 m"""
+    rng = np.random.default_rng(4)
+    n = 0
+    for _ in range(400):
+        p = rng.uniform(-1, 1, (int(rng.integers(4, 12)), 3)).astype(np.float32) * np.float32([1.0, 0.55, 0.25]) + np.float32(rng.uniform(-40, 40, 3))
+        (c0, s0, e0), (c1, s1, _) = _moie_call(oracle, p, 0), _moie_call(oracle, p, 1)
+        if min(e0[0] - e0[1], e0[1] - e0[2]) < 0.05 * e0[0]:
+            continue  # nearly repeated eigenvalue: the basis, hence the box, is the solver's choice
+        n += 1
+        np.testing.assert_allclose(c0, c1, atol=1e-3)
+        assert abs(s0 - s1) < 1e-3
+    assert n > 200
+
+
+def test_obb_gates_on_degenerate_lattice_clusters(oracle):
+    """The shapes MAV-sized clusters take (min_points 2): repeated eigenvalues everywhere.  Axis-aligned shapes have an exactly
+    diagonal covariance: both solvers return the coordinate axes and identical boxes.  A repeated eigenvalue whose
+    eigen-space is NOT axis aligned (the lattice tetrahedron) is where a symmetric solver and the general one pick different
+    bases: the centre moves by centimetres - the reason product and oracle follow the EigenSolver path."""
+    vs = 0.25
+    max_size, max_explore = 3.0, 3.0  # config/detection_params.yaml:52,56
+    import itertools
+
+    aligned = {
+        "2 points along x": [(0, 0, 0), (1, 0, 0)],
+        "3 collinear": [(0, 0, 0), (1, 0, 0), (2, 0, 0)],
+        "2x2 square": [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)],
+        "2x2 square xz": [(0, 0, 0), (1, 0, 0), (0, 0, 1), (1, 0, 1)],
+        "2x2x2 cube": list(itertools.product((0, 1), repeat=3)),
+        "3x3 square": [(i, j, 0) for i in range(3) for j in range(3)],
+        "plus": [(1, 0, 0), (0, 1, 0), (1, 1, 0), (2, 1, 0), (1, 2, 0)],
+    }
+    want_size = {"2 points along x": vs, "3 collinear": 2 * vs, "2x2 square": math.sqrt(2) * vs, "2x2 square xz": math.sqrt(2) * vs,
+                 "2x2x2 cube": math.sqrt(3) * vs, "3x3 square": 2 * math.sqrt(2) * vs, "plus": 2 * math.sqrt(2) * vs}
+    for name, cells in aligned.items():
+        p = _lattice(cells, vs)
+        (c0, s0, _), (c1, s1, _) = _moie_call(oracle, p, 0), _moie_call(oracle, p, 1)
+        np.testing.assert_allclose(c0, p.mean(0), atol=1e-5, err_msg=name)  # symmetric shapes: centre = centroid
+        np.testing.assert_allclose(c0, c1, atol=1e-6, err_msg=name)
+        assert s0 == pytest.approx(want_size[name], rel=1e-5), name
+        assert s1 == pytest.approx(s0, rel=1e-6), name
+        assert (s0 > max_size) == (s1 > max_size)
+        assert int((s0 + max_explore) / vs) == int((s1 + max_explore) / vs)
+    # diagonal pairs / triples: one non-zero eigenvalue, a two-fold zero one; the extent along the cluster's line decides
+    for cells, length in (([(0, 0, 0), (1, 1, 0)], math.sqrt(2) * vs), ([(0, 0, 0), (1, 1, 1)], math.sqrt(3) * vs), ([(0, 0, 0), (1, 1, 0), (2, 2, 0)], 2 * math.sqrt(2) * vs)):
+        p = _lattice(cells, vs)
+        for solver in (0, 1):
+            c, s, _ = _moie_call(oracle, p, solver)
+            np.testing.assert_allclose(c, p.mean(0), atol=1e-4)
+            assert s == pytest.approx(length, rel=1e-4)
+    # the lattice tetrahedron: eigenvalues (a, a, b) with a skew two-dimensional eigen-space
+    p = _lattice([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)], vs)
+    (c0, s0, e0), (c1, s1, e1) = _moie_call(oracle, p, 0), _moie_call(oracle, p, 1)
+    assert e0[0] == pytest.approx(e0[1], rel=1e-5) and e0[1] > 3 * e0[2]
+    assert np.abs(c0 - c1).max() > 0.02  # the solvers' boxes differ by centimetres ...
+    assert abs(s0 - s1) < 0.01           # ... while the gated diagonal hardly moves
+    assert (s0 > max_size) == (s1 > max_size) and int((s0 + max_explore) / vs) == int((s1 + max_explore) / vs)
+    # whatever the basis, the box of the general solver contains the points: centre within the AABB, diagonal between the
+    # largest pairwise distance and the AABB's diagonal + one voxel
+    rng = np.random.default_rng(9)
+    for _ in range(500):
+        cells = np.unique(rng.integers(0, 3, size=(int(rng.integers(2, 10)), 3)), axis=0)
+        if len(cells) < 2:
+            continue
+        p = _lattice(cells, vs, off=rng.uniform(-50, 50, 3))
+        c, s, _ = _moie_call(oracle, p, 0)
+        assert np.all(c >= p.min(0) - 1e-3) and np.all(c <= p.max(0) + 1e-3)
+        far = max(np.linalg.norm(a - b) for a in p for b in p)
+        assert far - 1e-3 <= s <= np.linalg.norm(p.max(0) - p.min(0)) * math.sqrt(3) + 1e-3
+
 
 def test_check_sensor_params(oracle):
     """vofod_nodelet.cpp:1869-1917: the first pixel with mask != 0 and range != 0 is compared with the LUT (direction,

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "eigsolve3.h"
 
 #ifdef __HIPCC__
 #define VT_HD __host__ __device__
@@ -102,50 +103,6 @@ struct Boxes
   float obb_min[3], obb_max[3], obb_center[3];
 };
 
-// symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations (host and device: the same IEEE operations in the same order)
-VT_HD inline void eig3(double a[3][3], double w[3], double v[3][3])
-{
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++)
-      v[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int it = 0; it < 60; it++)
-  {
-    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
-    if (off <= 1e-36 * diag || off < 1e-280)  // off-diagonal below double resolution of the diagonal (avoids denormal sweeps)
-      break;
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 3; q++)
-      {
-        if (a[p][q] == 0.0)
-          continue;
-        const double tau = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        const double t = (tau >= 0.0 ? 1.0 : -1.0) / ((tau < 0.0 ? -tau : tau) + sqrt(1.0 + tau * tau));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-        for (int k = 0; k < 3; k++)
-        {
-          const double x = a[k][p], y = a[k][q];
-          a[k][p] = c * x - s * y;
-          a[k][q] = s * x + c * y;
-        }
-        for (int k = 0; k < 3; k++)
-        {
-          const double x = a[p][k], y = a[q][k];
-          a[p][k] = c * x - s * y;
-          a[q][k] = s * x + c * y;
-        }
-        for (int k = 0; k < 3; k++)
-        {
-          const double x = v[k][p], y = v[k][q];
-          v[k][p] = c * x - s * y;
-          v[k][q] = s * x + c * y;
-        }
-      }
-  }
-  for (int i = 0; i < 3; i++)
-    w[i] = a[i][i];
-}
-
 // [3P] pcl::MomentOfInertiaEstimation: mean, covariance/n^2, principal axes (major >= middle >= minor,
 // right-handed), AABB and OBB (centre = mean + R*shift).  Members in ascending index order; `get(i, p)` fetches the centre
 // of member i.  Host (classification tail, fallback) and device (k_tail_prep) run this very function.
@@ -184,11 +141,12 @@ VT_HD inline Boxes boxes_of_n(size_t n, Get get)
         cov[r][q] += c[r] * c[q];
   }
   const float mass = 1.0f / static_cast<float>(n * n);
-  double A[3][3], w[3], V[3][3];
   for (int r = 0; r < 3; r++)
     for (int q = 0; q < 3; q++)
-      A[r][q] = cov[r][q] * mass;
-  eig3(A, w, V);
+      cov[r][q] *= mass;
+  // computeEigenVectors: Eigen::EigenSolver<Matrix3f> (eigsolve3.h), eigenvalues' real parts ordered major >= middle >= minor
+  float w[3], V[3][3];
+  ve::eigsolve3(cov, w, V);
   int ord[3] = {0, 1, 2};
   if (w[ord[0]] < w[ord[1]])
   {
@@ -211,7 +169,7 @@ VT_HD inline Boxes boxes_of_n(size_t n, Get get)
   float ax[3][3];
   for (int k = 0; k < 3; k++)
   {
-    float u[3] = {static_cast<float>(V[0][ord[k]]), static_cast<float>(V[1][ord[k]]), static_cast<float>(V[2][ord[k]])};
+    float u[3] = {V[0][ord[k]], V[1][ord[k]], V[2][ord[k]]};
     const float nn = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     for (int a = 0; a < 3; a++)
       ax[k][a] = u[a] / nn;
