@@ -429,7 +429,6 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_key": 12.0 * n_pts * F,
         "k_slab": 4.0 * V * F,
         "k_slab_emit": 28.0 * V * F,
-        "k_brick_ccl_lds": 16.0 * V * F,
         "k_flatten<2>": 8.0 * V * F,
         "k_count": 12.0 * n_pts * F,
         "k_emit": 20.0 * V * F,

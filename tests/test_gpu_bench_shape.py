@@ -187,7 +187,7 @@ def test_large_batch_falls_back_per_batch_when_a_frame_overflows_lds(oracle, hip
         lib.profile_enable(dev.h, 0)
         lds_off = os.environ.get("VOFOD_CCL") == "voxel" or os.environ.get("VOFOD_BRICK_LDS") == "0"  # (no LDS clustering: no frame kernel either)
         if batch == 1 and not lds_off:  # (tools/run_fallback_matrix.sh switches the LDS kernels off altogether)
-            assert any(n.startswith(("k_brick_ccl_lds", "k_frame_lds")) for n in names), names  # no permanent latch
+            assert any(n.startswith("k_frame_lds") for n in names), names  # no permanent latch
 
 
 def _profiled_kernels(lib, det):

@@ -227,8 +227,9 @@ def test_no_map_update_and_batch_parity(oracle, hip):
 
 
 def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, monkeypatch):
-    """0.25 m voxels, tolerance 1.5 m: bricks are cliques, batches of >= 4 frames cluster inside LDS (k_brick_ccl_lds);
-    a frame with more bricks than the kernel takes makes the host run the batch again on the global-memory kernels."""
+    """0.25 m voxels, tolerance 1.5 m: bricks are cliques, batches of >= 4 frames are voxelised and clustered inside LDS
+    (k_key1 -> k_frame_lds); a frame with more bricks than the kernel takes makes the host run the batch again on the
+    general kernels (slab voxeliser + global-memory brick clustering)."""
     scene = synth.make_scene(41, n_targets=3)
     scans = synth.scan_sequence(scene, "os1-128", 6, seed0=700)
     tfs = np.stack([s.tf for s in scans])
@@ -261,8 +262,9 @@ def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, 
 
 @pytest.mark.parametrize("voxel_size", [0.25, 0.5])
 def test_large_batch_takes_the_fused_slab_emission(oracle, hip, voxel_size):
-    """>= 128 frames per batch: k_slab_emit (bitmap slab in LDS -> voxel records) replaces k_slab + k_scan_b + k_emit;
-    0.25 m: brick clustering in LDS follows, 0.5 m: the voxel-level clustering kernels (they read the whole prefix array)"""
+    """>= 128 frames per batch.  0.25 m: bricks are cliques -> the frame kernel (k_key1 -> k_frame_lds); 0.5 m: voxel-level
+    clustering -> the general path, whose large-batch form is k_slab_emit (bitmap slab in LDS -> voxel records, instead of
+    k_slab + k_scan_b + k_emit) followed by k_union<2> (which reads the whole prefix array)"""
     ref, dev = make_pair(oracle, hip, "os1-16", voxel_size, max_batch=136)
     for d in (ref, dev):
         synth.seed_ground(d)
@@ -296,8 +298,9 @@ def _dense_scan(sensor, seed, extent, empty=False):
 
 @pytest.mark.parametrize("n_frames", [6, 130])
 def test_batches_of_dense_and_empty_frames(oracle, hip, n_frames):
-    """stress of the slab voxeliser's side paths: key lists longer than the register file (> 48 Ki survivors), more
-    extras than the LDS staging area, an empty frame in the middle of a batch; both batch forms (k_slab / k_slab_emit)"""
+    """stress of the batch voxelisers' side paths (the frame kernel at 0.25 m, its overflow re-run on the slab voxeliser): key
+    lists longer than a workgroup's register file (> 48 Ki survivors), voxels with more points than a byte counter holds, an
+    empty frame in the middle of a batch; both batch sizes (< / >= 128 frames)"""
     sensor = "os1-128" if n_frames == 6 else "os1-16"
     ref, dev = make_pair(oracle, hip, sensor, 0.25, max_batch=n_frames)
     for d in (ref, dev):

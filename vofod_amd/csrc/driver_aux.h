@@ -1052,7 +1052,7 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
     size_t got = 0;
     int r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
                            n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
-    if (r == CCL_RETRY_STATUS)  // see k_brick_ccl_lds: once per handle at most
+    if (r == CCL_RETRY_STATUS)  // a frame beyond the LDS capacities of k_frame_lds: this batch once more, on the global kernels
       r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
                          n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
     for (size_t i = total; i < std::min(total + got, cap); i++)
@@ -1113,7 +1113,7 @@ int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_
   int r = process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);
   if (r == CCL_RETRY_STATUS)
   {
-    // see k_brick_ccl_lds: the batch is enqueued again (global-memory clustering) from the submitted descriptors
+    // a frame beyond the LDS capacities of k_frame_lds: the batch is enqueued again (global-memory clustering) from the submitted descriptors
     r = process_frames(h, w, FRAMES_LAUNCH, w.job_scans.data(), w.job_tfs.data(), w.job_n, VOFOD_SCAN_NO_MAP_UPDATE, nullptr, 0, nullptr, nullptr, nullptr);
     if (r == VOFOD_OK)
       r = process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);

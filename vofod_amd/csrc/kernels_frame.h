@@ -2,7 +2,7 @@
 //
 // Round 1's batched path walked the frame's 11 M-cell lattice in 1 Mi-cell LDS slabs (k_slab_emit: 11 x clear + mark +
 // scan of 128 KB, 1400 emission groups, 99.7 % of them empty) and then re-derived the brick graph from the voxel
-// records in a second kernel (k_brick_ccl_lds, phases A-C).  The lattice is sparse, the *brick* lattice (4x4x4 cells
+// records in a second LDS kernel (retired in round 3).  The lattice is sparse, the *brick* lattice (4x4x4 cells
 // per brick, 64 times fewer bits) is not large: a whole frame's brick bitmap fits LDS next to its occupied bricks.
 // So voxelisation (voxel_grid_weighted.cpp:122-188) runs brick-first and the clustering (vofod_nodelet.cpp:689-698)
 // continues on the very same LDS image:
@@ -20,7 +20,7 @@
 //                  go through a small per-frame table in global memory (L2) and one block scan in key order gives
 //                  every lattice row its base rank; then the voxel records (centre, weight 1, key, node) are stored
 //                  at their ranks and the extras add to their voxels' weights,
-//               D-E the clustering phases of k_brick_ccl_lds on the same bitmap / words (probe, octant test, exact test
+//               D-E the clustering phases on the same bitmap / words (probe, octant test, exact test
 //                  across components only, LDS union-find, component minima, statistics, labels, cluster table).
 // A frame beyond the LDS capacities raises CCL_RETRY_STATUS: the host re-runs that batch on the general kernels.
 #pragma once
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   FR_STAMP(7);
   constexpr int VU = 8;  // voxel records fetched per lane and round in the label pass
   const uint32_t Vround = (V + 63u) & ~63u;
-  // ---- D: probe, test, union (the phases of k_brick_ccl_lds; the bitmap's prefix is per 64-bit word here).
+  // ---- D: probe, test, union (the bitmap's prefix is per 64-bit word).
   // D-a: every (brick, stencil row) reads one window of the brick bitmap; occupied neighbours go to the hit list.
   // D-b: adjacent-brick hits first (octant matrices, unions), flatten, then the hits two bricks away: most of them now join
   //      bricks of one component and are dismissed by two LDS reads.  Pairs the octant matrices leave open are collected.
@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     if (my_root[r] != 0xffffffffu)
       atomicMin(&s_cmin[my_root[r]], my_min[r]);
   __syncthreads();
-  // ---- cluster statistics (size, lattice box, close flag) brick by brick, as k_brick_ccl_lds
+  // ---- cluster statistics (size, lattice box, close flag) brick by brick
   uint16_t* s_cidx = reinterpret_cast<uint16_t*>(s_word + LB_MAX / 2);               // node (root) -> component index
   uint32_t* st_label = reinterpret_cast<uint32_t*>(s_cidx + LB_MAX);                 // LB_ST_ROWS x {label, count, close, box[6]}
   uint32_t* st_cnt = st_label + LB_ST_ROWS;

@@ -536,7 +536,7 @@ struct vofod_handle
     BrickOff* d_boffs = nullptr;
     unsigned long long *d_sure = nullptr, *d_amb = nullptr;
     int8_t* d_pair = nullptr;  // [64*64] stencil index of offset(o2) - offset(o1), -1 when outside the forward stencil
-    LbTables* d_lbtab = nullptr;  // row / octant tables of k_brick_ccl_lds
+    LbTables* d_lbtab = nullptr;  // row / octant tables of the LDS clustering (k_frame_lds)
     bool lds_ok = false;
   } ctab[2];
   int ctab_next = 0;
@@ -712,7 +712,7 @@ bool build_brick_tables(const float leaf[3], float tol, float cmax, std::vector<
   return true;
 }
 
-// Tables of k_brick_ccl_lds derived from the brick stencil: the offsets grouped into (dy,dz) rows, and per offset two
+// Tables of the LDS clustering (k_frame_lds) derived from the brick stencil: the offsets grouped into (dy,dz) rows, and per offset two
 // 8x8 bit matrices over 2x2x2 octants: sure8 (every voxel pair of the two octants is certainly within the tolerance)
 // and maybe8 (some pair is, certainly or on the boundary).
 bool build_lds_tables(const EdgeClassifier& classify, const std::vector<BrickOff>& offs, const std::vector<unsigned long long>& sure, const std::vector<unsigned long long>& amb,
@@ -1021,12 +1021,13 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   // lean emission: the LDS clustering kernel will follow and initialises the per-root slots itself (see plan_lds_ccl)
   ws.lean_emit = lean_hint && !bricks && !g.xcd_map && !two_phase;
   ws.slab_bitmap = false;
-  const uint32_t lean_bit = ws.lean_emit ? 0x80000000u : 0u;
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   const uint32_t gb = std::max(1u, std::min((max_pts + 2047u) / 2048u, 1024u));  // 8 points per thread: few header atomics
-  static const bool frame_on = !(std::getenv("VOFOD_FRAME_LDS") && std::atoi(std::getenv("VOFOD_FRAME_LDS")) == 0);
-  const bool frame_plan = frame_on && ws.lean_emit && n >= 4 && !want_ptrank && !two_phase;
+  const bool frame_plan = ws.lean_emit && n >= 4 && !want_ptrank && !two_phase;
+  if (!frame_plan)
+    ws.lean_emit = false;  // the general emission kernels initialise every per-voxel slot; the global clustering kernels follow
+  const uint32_t lean_bit = ws.lean_emit ? 0x80000000u : 0u;
   ws.ref_lattice = RefLattice{};
   if (frame_plan)
     ws.ref_lattice = fill_ref_lattice(g);
@@ -1055,7 +1056,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
   // Batches whose clustering will run inside LDS (plan_lds_ccl): brick-first frame kernel (kernels_frame.h).  One pass over
   // the input writes the survivors' brick codes; k_frame_lds (launched by launch_cluster) builds the voxel records and
-  // clusters them on the same LDS image.  VOFOD_FRAME_LDS=0 keeps the slab voxeliser + k_brick_ccl_lds of round 1.
+  // clusters them on the same LDS image.
   ws.frame_fused = false;
   if (frame_plan)
   {
@@ -1354,21 +1355,9 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
         HIPCHK(hipGetLastError());
         return VOFOD_OK;
       }
-      KLAUNCH(h, k_brick_ccl_lds, dim3(n), dim3(LB_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.va, ws.d_labels, ws.d_bitmaps, ws.d_wprefix, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table),
-              h->mg, mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof);
-      ws.finalize_fused = up_tables && mapclose;  // cluster table + candidate members written as well (k_finalize's part for read-only batches)
-      if (d_prof)
-      {
-        // VOFOD_LDS_PROF=1 (diagnostics): phase durations of frame 0 from the 100 MHz wall clock
-        unsigned long long t[16];
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(t, d_prof, sizeof(t), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[k_brick_ccl_lds] n %llu hits %llu open %llu | A %.1f B %.1f C %.1f Da %.1f Db %.1f Dc %.1f E %.1f label %.1f us\n", t[11], t[9], t[10], (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[7] - t[3]) * 0.01, (t[8] - t[7]) * 0.01, (t[4] - t[8]) * 0.01,
-                     (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01);
-      }
-      ws.closefar_fused = mapclose != nullptr;  // the kernel gathered the cluster statistics and answered hasCloseTo as well
-      HIPCHK(hipGetLastError());
-      return VOFOD_OK;
+      // (lean_emit without the frame kernel cannot happen: launch_voxelize clears it when it does not plan the frame path)
+      h->err = "internal: lean emission without the frame kernel";
+      return VOFOD_ERR_DEVICE;
     }
     if (!ws.bricks_preset)
       KLAUNCH(h, k_brick_set, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
