@@ -295,6 +295,60 @@ def _dense_scan(sensor, seed, extent, empty=False):
         z = rng.uniform(-2.0, 1.0, n).astype(np.float32)
     return ScanData(x=x, y=y, z=z.copy(), width=w, height=h, stride_bytes=4)
 
+@pytest.mark.parametrize("n_frames,max_batch,want_slabs", [(4, 36, True), (10, 32, True), (6, 6, False)])
+def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch, want_slabs):
+    """Batches that would leave most CUs idle with one workgroup per frame: every frame is cut into y-slabs (k_frame_lds<true>,
+    one workgroup per slab with a halo, k_slab_merge joins them).  The ground sheet and the buildings span every slab, so the
+    largest component of every frame is stitched across all cuts; an empty and a dense frame ride along.  Everything the
+    debug output carries (weighted cloud, labels, cluster table, detections) equals the oracle's."""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=max_batch)
+    scene = synth.make_scene(77, n_targets=3)
+    ap = synth.apriori_points(scene, 0.25)
+    for d in (ref, dev):
+        d.load_apriori(ap)  # both latches: classification and flood fills run
+    base = synth.scan_sequence(synth.make_scene(77, n_targets=6), "os1-128", n_frames, seed0=4100)
+    scans = [s.scan for s in base]
+    tfs = np.stack([s.tf for s in base])
+    scans[1] = _dense_scan("os1-128", 6, 20.0)             # points all over a 40 m square: many bricks in every slab
+    if n_frames > 4:
+        scans[3] = _dense_scan("os1-128", 7, 1.0, empty=True)
+    lib = dev.lib
+    lib.profile_enable(dev.h, 1)
+    db, pb, gb = dev.process_batch(scans, tfs, debug=True, clusters_cap=65536)
+    names = []
+    if not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK"):
+        buf, ms, calls = (C.c_char * (64 * 96))(), (C.c_double * 96)(), (C.c_uint64 * 96)()
+        n = lib.profile_read(dev.h, buf, ms, calls, 96)
+        names = [buf[64 * i : 64 * i + 64].split(b"\0", 1)[0].decode() for i in range(n)]
+    lib.profile_enable(dev.h, 0)
+    da, pa, ga = ref.process_batch(scans, tfs, debug=True, clusters_cap=65536)
+    np.testing.assert_array_equal(pb, pa)
+    assert_detections_equal(da, db)
+    for k, (x, y) in enumerate(zip(ga, gb)):
+        try:
+            assert_scan_debug_equal(x, y)
+        except AssertionError as e:
+            raise AssertionError(f"frame {k}: {e}") from e
+    assert max(len(g["clusters"]) for g in ga) > 20
+    if names and os.environ.get("VOFOD_SLABS_PER_FRAME") in (None, "") and os.environ.get("VOFOD_BRICK_LDS") != "0" and os.environ.get("VOFOD_CCL") != "voxel" and os.environ.get("VOFOD_DILATE") != "0":
+        assert ("k_slab_merge" in names) == want_slabs, names
+    # without debug output (device tail) and pipelined: the same detections
+    got, per = dev.process_batch(scans, tfs)
+    np.testing.assert_array_equal(per, pa)
+    assert_detections_equal(da, _rebase_ids(got, da))
+    t0, t1 = dev.batch_submit(scans, tfs), dev.batch_submit(scans, tfs)
+    for t in (t0, t1):
+        g, per = dev.batch_collect(t)
+        np.testing.assert_array_equal(per, pa)
+        assert_detections_equal(da, _rebase_ids(g, da))
+
+
+def _rebase_ids(got, want):
+    got = got.copy()
+    if len(got) and len(want):
+        got["id"] += want["id"][0] - got["id"][0]
+    return got
+
 
 @pytest.mark.parametrize("n_frames", [6, 130])
 def test_batches_of_dense_and_empty_frames(oracle, hip, n_frames):

@@ -66,7 +66,10 @@ def main():
                 mask = mask_layout(hip, (rng.random((hh, ww)) < rng.uniform(0.5, 1.0)).astype(np.uint8), ww, hh, rng.integers(0, 16, hh).astype(np.int32))
                 dyn["raycast__min_intensity"] = float(rng.choice([0.0, 100.0, 500.0]))
                 desc += f" calibrated lut+mask, min_intensity {dyn['raycast__min_intensity']}"
-            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch, lut=lut, mask=mask, **dyn)
+            # spare workspace slots let small batches split their frames into slabs (k_frame_lds<true> + k_slab_merge)
+            cap_mult = int(rng.choice([1, 3, 4, 9])) if n_batch <= 17 else 1
+            desc += f" slots x{cap_mult}"
+            ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch * cap_mult, lut=lut, mask=mask, **dyn)
             scene = synth.make_scene(int(rng.integers(0, 10_000)), n_targets=int(rng.integers(0, 4)))
             if use_apriori:
                 ap_pts = synth.apriori_points(scene, voxel)
@@ -126,7 +129,8 @@ def main():
             sb = status_of(lambda: dev.raycast_begin(s.scan, s.tf))
             assert sa == sb, f"raycast_begin status {sa} (oracle) vs {sb} (HIP)"
             if sa == capi.OK:
-                np.testing.assert_allclose(dev.read_map(capi.MAP_RAYCAST), ref.read_map(capi.MAP_RAYCAST), rtol=2e-5, atol=2e-6)
+                # tolerance: float-atomic accumulation order; near the sensor a voxel collects thousands of path segments (H8)
+                np.testing.assert_allclose(dev.read_map(capi.MAP_RAYCAST), ref.read_map(capi.MAP_RAYCAST), rtol=2e-4, atol=2e-6)
         except Exception as e:  # noqa: BLE001
             print(f"MISMATCH at {desc}\n{type(e).__name__}: {str(e)[:1500]}", flush=True)
             return 1

@@ -45,6 +45,7 @@ struct FrameHdr
   uint32_t need_words;  // bitmap words the lattice needs (reported even when it exceeds the workspace)
   uint32_t n_bricks;    // occupied 4x4x4 bricks (brick-level clustering)
   uint32_t n_undecided; // voxels whose own map row is empty: k_closefar_sweep tests their whole stencil
+  int32_t slab_y0, slab_y1;  // frames split into y-slabs (k_frame_lds<true>): the lattice rows [y0, y1) this slab owns
 };
 
 // Parameters constant over a call (passed by value).

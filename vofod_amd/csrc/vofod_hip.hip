@@ -342,7 +342,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave, fs.planes, fs.cuts};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -429,6 +429,8 @@ struct Workspace
     WS_ALLOC(fs.bmin, sizeof(uint32_t) * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.nodeA, sizeof(unsigned long long) * 4 * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.bbsave, sizeof(unsigned long long) * FR_BB64 * static_cast<size_t>(F));
+    WS_ALLOC(fs.planes, sizeof(uint32_t) * 3 * FR_PLANES * static_cast<size_t>(F));
+    WS_ALLOC(fs.cuts, sizeof(int32_t) * (FR_SLABS_MAX + 2) * static_cast<size_t>(F));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -1311,19 +1313,16 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       if (ws.frame_fused)
       {
         ws.frame_fused = false;
-        KLAUNCH(h, k_frame_lds, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose,
-                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args);
-        ws.finalize_fused = up_tables && mapclose;
-        if (d_prof)
-        {
+        auto print_prof = [&](uint32_t s0, uint32_t cnt) -> int {
+
           // VOFOD_LDS_PROF=1 (diagnostics): phase durations from the 100 MHz wall clock
-          std::vector<unsigned long long> t(32 * n);
+          std::vector<unsigned long long> t(32 * cnt);
           HIPCHK(hipStreamSynchronize(h->stream));
-          HIPCHK(hipMemcpy(t.data(), d_prof, sizeof(unsigned long long) * 32 * n, hipMemcpyDeviceToHost));
+          HIPCHK(hipMemcpy(t.data(), d_prof + 32 * static_cast<size_t>(s0), sizeof(unsigned long long) * 32 * cnt, hipMemcpyDeviceToHost));
           static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "adjacent", "far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
           std::vector<std::pair<double, uint32_t>> byd;
           unsigned long long t0 = ~0ull, t1 = 0;
-          for (uint32_t f = 0; f < n; f++)
+          for (uint32_t f = 0; f < cnt; f++)
           {
             if (!t[32 * f + 13])
               continue;
@@ -1349,8 +1348,41 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           }
           if (!byd.empty())
             std::fprintf(stderr, "[k_frame_lds] %zu workgroups: span %.1f us, mean %.1f us\n", byd.size(), (t1 - t0) * 0.01, mean);
-          HIPCHK(hipMemset(d_prof, 0, sizeof(unsigned long long) * 32 * n));
+          HIPCHK(hipMemset(d_prof + 32 * static_cast<size_t>(s0), 0, sizeof(unsigned long long) * 32 * cnt));
+                  return VOFOD_OK;
+        };
+        // Batches that leave most CUs idle under one workgroup per frame: each frame is split into y-slabs, one workgroup per
+        // slab (k_frame_lds<true>), the slabs' results joined by k_slab_merge.  Slab s of frame f uses slot n + f * S + s of the
+        // workspace, so the split is as deep as the free slots allow (32 frames in a 256-frame workspace: 7 slabs).
+        // VOFOD_SLABS_PER_FRAME=1 keeps one workgroup per frame; =N caps the depth.
+        static const int slabs_env = std::getenv("VOFOD_SLABS_PER_FRAME") ? std::atoi(std::getenv("VOFOD_SLABS_PER_FRAME")) : FR_SLABS_MAX;
+        // (how deep: every slab workgroup repeats the per-frame fixed costs - the pass over the frame's codes, table set-up - so
+        // the cheapest split for the throughput of batches in flight is not the deepest; about 128 workgroups per batch)
+        static const uint32_t slab_wgs = std::getenv("VOFOD_SLAB_WGS") ? std::max(1, std::atoi(std::getenv("VOFOD_SLAB_WGS"))) : 128u;
+        uint32_t n_slabs = 1;
+        if (n < 128u && up_tables && mapclose && ws.ref_lattice.on && ws.F >= 3u * n)
+          n_slabs = std::min<uint32_t>({static_cast<uint32_t>(std::max(slabs_env, 1)), static_cast<uint32_t>(FR_SLABS_MAX), ws.F / n - 1u, std::max(1u, slab_wgs / n)});
+        if (n_slabs >= 2)
+        {
+          KLAUNCH(h, k_slab_cuts, dim3(n), dim3(1024), g, bp, ws.d_hdrs, ws.sa, ws.pt_cap, ws.fs, ws.ref_lattice, n_slabs);
+          KLAUNCH(h, k_frame_lds<true>, dim3(n * n_slabs), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
+                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, n_slabs);
+          KLAUNCH(h, k_slab_merge, dim3(n), dim3(SM_THREADS), g, ws.d_hdrs, ws.va, ws.d_table, ws.fs, n, n_slabs, *up_tables);
+          KLAUNCH(h, k_slab_gather, dim3(n * n_slabs), dim3(SG_THREADS), g, ws.d_hdrs, ws.va, ws.d_labels, ws.d_cand, ws.fs, n, n_slabs);
+          if (d_prof)
+            if (const int pr = print_prof(n, n * n_slabs); pr != VOFOD_OK)
+              return pr;
+          ws.finalize_fused = true;
+          ws.closefar_fused = true;
+          HIPCHK(hipGetLastError());
+          return VOFOD_OK;
         }
+        KLAUNCH(h, k_frame_lds<false>, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose,
+                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, n, 1u);
+        ws.finalize_fused = up_tables && mapclose;
+        if (d_prof)
+          if (const int pr = print_prof(0, n); pr != VOFOD_OK)
+            return pr;
         ws.closefar_fused = mapclose != nullptr;
         HIPCHK(hipGetLastError());
         return VOFOD_OK;
