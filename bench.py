@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200, help="a step lasts ~0.5 ms")
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps (first-use work of the runtime: queues, code objects)")
     ap.add_argument("--frames", type=int, default=256, help="independent scans per GPU per step (one workgroup per frame clusters in LDS: 256 frames fill the 256 CUs)")
+    ap.add_argument("--max-batch", type=int, default=0, help="frame slots of the handle's workspaces (default: --frames); spare slots let small batches split their frames into slabs")
     ap.add_argument("--voxel-size", type=float, default=0.25)
     ap.add_argument("--sensor", default="os1-128")
     ap.add_argument("--map-warm-scans", type=int, default=96)
@@ -139,7 +140,7 @@ def main():
 
     lib = vofod_amd.library()
     F = args.frames if args.scaling == "weak" else max(4, args.frames // world)
-    det = build_detector(lib, args.sensor, args.voxel_size, F, local_rank)
+    det = build_detector(lib, args.sensor, args.voxel_size, max(F, args.max_batch), local_rank)
     scene = synth.bench_scene()
     synth.warm_map(det, scene, args.sensor, args.map_warm_scans)
 
@@ -223,12 +224,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get("VOFOD_BENCH_GC") == "off":  # diagnostics
-        import gc
+    # The timed loops are a few hundred Python calls into the C library; a cyclic-garbage collection of the interpreter (torch
+    # and numpy have loaded hundreds of thousands of objects) in the middle of one costs ~40 ms - seventy steps' worth.  The
+    # harness's collector is parked for the measurement; nothing below creates reference cycles.
+    import gc
 
-        gc.collect()
-        gc.freeze()
-        gc.disable()
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     if args.warmup:
         run_steps(args.warmup)
     sync()

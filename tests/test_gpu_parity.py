@@ -296,11 +296,12 @@ def _dense_scan(sensor, seed, extent, empty=False):
     return ScanData(x=x, y=y, z=z.copy(), width=w, height=h, stride_bytes=4)
 
 @pytest.mark.parametrize("n_frames,max_batch,want_slabs", [(4, 36, True), (10, 32, True), (6, 6, False)])
-def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch, want_slabs):
+def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch, want_slabs, monkeypatch):
     """Batches that would leave most CUs idle with one workgroup per frame: every frame is cut into y-slabs (k_frame_lds<true>,
     one workgroup per slab with a halo, k_slab_merge joins them).  The ground sheet and the buildings span every slab, so the
     largest component of every frame is stitched across all cuts; an empty and a dense frame ride along.  Everything the
     debug output carries (weighted cloud, labels, cluster table, detections) equals the oracle's."""
+    monkeypatch.setenv("VOFOD_SLABS_PER_FRAME", "8")  # the slab path is opt-in
     ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=max_batch)
     scene = synth.make_scene(77, n_targets=3)
     ap = synth.apriori_points(scene, 0.25)
@@ -330,7 +331,7 @@ def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch,
         except AssertionError as e:
             raise AssertionError(f"frame {k}: {e}") from e
     assert max(len(g["clusters"]) for g in ga) > 20
-    if names and os.environ.get("VOFOD_SLABS_PER_FRAME") in (None, "") and os.environ.get("VOFOD_BRICK_LDS") != "0" and os.environ.get("VOFOD_CCL") != "voxel" and os.environ.get("VOFOD_DILATE") != "0":
+    if names and os.environ.get("VOFOD_BRICK_LDS") != "0" and os.environ.get("VOFOD_CCL") != "voxel" and os.environ.get("VOFOD_DILATE") != "0":
         assert ("k_slab_merge" in names) == want_slabs, names
     # without debug output (device tail) and pipelined: the same detections
     got, per = dev.process_batch(scans, tfs)

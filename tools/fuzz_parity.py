@@ -30,6 +30,9 @@ def main():
     from vofod_amd import capi, synth
     from vofod_amd.detector import VofodError
 
+    import os
+
+    os.environ.setdefault("VOFOD_SLABS_PER_FRAME", "8")  # the opt-in slab path is part of the sweep (batches with spare slots)
     hip = vofod_amd.library()
     oracle = capi.Library(ROOT / "oracle" / "libvofod_oracle.so", "vofod_oracle_")
     t_end = time.time() + args.seconds

@@ -669,12 +669,12 @@ void vofod_destroy(vofod_handle* h)
   for (void* p : ptrs)
     if (p)
       (void)hipFree(p);
-  for (void* p : {static_cast<void*>(h->explore.d_overlay), static_cast<void*>(h->explore.d_stack), static_cast<void*>(h->explore.d_explored),
-                  static_cast<void*>(h->explore.d_touched), static_cast<void*>(h->explore.d_ovl_list), static_cast<void*>(h->explore.d_ovl_count),
-                  static_cast<void*>(h->explore.d_job_begin), static_cast<void*>(h->explore.d_jobs), static_cast<void*>(h->explore.d_results),
-                  static_cast<void*>(h->explore.d_members)})
-    if (p)
-      (void)hipFree(p);
+  for (ExploreBufs* e : {&h->explore})
+    for (void* p : {static_cast<void*>(e->d_overlay), static_cast<void*>(e->d_stack), static_cast<void*>(e->d_explored), static_cast<void*>(e->d_touched), static_cast<void*>(e->d_ovl_list),
+                    static_cast<void*>(e->d_ovl_count), static_cast<void*>(e->d_job_begin), static_cast<void*>(e->d_visited), static_cast<void*>(e->d_jobs), static_cast<void*>(e->d_results),
+                    static_cast<void*>(e->d_members)})
+      if (p)
+        (void)hipFree(p);
   for (auto& c : h->ctab)
     for (void* p : {static_cast<void*>(c.d_rows), static_cast<void*>(c.d_boffs), static_cast<void*>(c.d_sure), static_cast<void*>(c.d_amb), static_cast<void*>(c.d_pair), static_cast<void*>(c.d_lbtab)})
       if (p)

@@ -2242,15 +2242,26 @@ __global__ __launch_bounds__(1024) void k_slab_cuts(const GridParams g, const Br
   const uint32_t n_ref = sa.counts[2 * F];
   const uint32_t* codes = sa.keys + static_cast<size_t>(F) * pt_cap;
   constexpr int KPT = 8;
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(codes) & 15u) == 0u;
   for (uint32_t base = tid * KPT; base < n_ref; base += 1024 * KPT)
   {
+    uint32_t cc[KPT];
+    if (vec_ok && base + KPT <= n_ref)
+    {
+      const uint4 a = *reinterpret_cast<const uint4*>(codes + base), b = *reinterpret_cast<const uint4*>(codes + base + 4);
+      cc[0] = a.x, cc[1] = a.y, cc[2] = a.z, cc[3] = a.w, cc[4] = b.x, cc[5] = b.y, cc[6] = b.z, cc[7] = b.w;
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+        cc[u] = base + u < n_ref ? codes[base + u] : FR_CODE_NONE;
+    }
     uint32_t cur = 0xffffffffu, cnt = 0;
 #pragma unroll
     for (int u = 0; u < KPT; u++)
     {
-      if (base + u >= n_ref)
-        break;
-      const uint32_t c = codes[base + u];
+      const uint32_t c = cc[u];
       const int k1 = static_cast<int>((c >> 11) & 2047u) - sh1;
       if (c == FR_CODE_NONE || static_cast<uint32_t>(k1) >= static_cast<uint32_t>(dv1))
         continue;

@@ -1354,14 +1354,14 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
         // Batches that leave most CUs idle under one workgroup per frame: each frame is split into y-slabs, one workgroup per
         // slab (k_frame_lds<true>), the slabs' results joined by k_slab_merge.  Slab s of frame f uses slot n + f * S + s of the
         // workspace, so the split is as deep as the free slots allow (32 frames in a 256-frame workspace: 7 slabs).
-        // VOFOD_SLABS_PER_FRAME=1 keeps one workgroup per frame; =N caps the depth.
-        static const int slabs_env = std::getenv("VOFOD_SLABS_PER_FRAME") ? std::atoi(std::getenv("VOFOD_SLABS_PER_FRAME")) : FR_SLABS_MAX;
-        // (how deep: every slab workgroup repeats the per-frame fixed costs - the pass over the frame's codes, table set-up - so
-        // the cheapest split for the throughput of batches in flight is not the deepest; about 128 workgroups per batch)
-        static const uint32_t slab_wgs = std::getenv("VOFOD_SLAB_WGS") ? std::max(1, std::atoi(std::getenv("VOFOD_SLAB_WGS"))) : 128u;
+        // Opt-in (VOFOD_SLABS_PER_FRAME=N, N >= 2: up to N slabs): measured on 32-frame batches the frame stage shrinks from
+        // 320 to 195 us (+ 60 us of cuts / merge / gather), but the rate of pipelined small batches is set by the latency of the
+        // cross-stream hand-offs, not by the kernels: 125 k frames/s with slabs, 131 k without.  One workgroup per frame stays
+        // the default; the slab path is kept (and tested) for callers that need the latency of a single small batch.
+        const int slabs_env = std::getenv("VOFOD_SLABS_PER_FRAME") ? std::atoi(std::getenv("VOFOD_SLABS_PER_FRAME")) : 1;
         uint32_t n_slabs = 1;
         if (n < 128u && up_tables && mapclose && ws.ref_lattice.on && ws.F >= 3u * n)
-          n_slabs = std::min<uint32_t>({static_cast<uint32_t>(std::max(slabs_env, 1)), static_cast<uint32_t>(FR_SLABS_MAX), ws.F / n - 1u, std::max(1u, slab_wgs / n)});
+          n_slabs = std::min<uint32_t>({static_cast<uint32_t>(std::max(slabs_env, 1)), static_cast<uint32_t>(FR_SLABS_MAX), ws.F / n - 1u});
         if (n_slabs >= 2)
         {
           KLAUNCH(h, k_slab_cuts, dim3(n), dim3(1024), g, bp, ws.d_hdrs, ws.sa, ws.pt_cap, ws.fs, ws.ref_lattice, n_slabs);
@@ -1472,9 +1472,8 @@ float map_cmax(const vofod_handle* h)
 int raycast_begin_locked(vofod_handle* h, const vofod_scan* scan, const float tf[12]);
 int raycast_finish_locked(vofod_handle* h);
 
-int ensure_explore(vofod_handle* h, uint32_t F, size_t n_jobs, size_t n_members)
+int ensure_explore(vofod_handle* h, ExploreBufs& eb, uint32_t F, size_t n_jobs, size_t n_members)
 {
-  ExploreBufs& eb = h->explore;
   const size_t ovl_words = (h->mg.n + 63) / 64;
   if (eb.F < F)
   {
@@ -1916,12 +1915,13 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     }
     if (h->n_bg_voxels > h->background_min_sufficient_pts)
       h->background_pts_sufficient = true;
-    r = ensure_explore(h, h->ws.F, static_cast<size_t>(h->ws.F) * vtd::TP_MAXC, static_cast<size_t>(h->ws.F) * vtd::TP_MAXM);
+    ExploreBufs& eb = h->explore;
+    r = ensure_explore(h, eb, h->ws.F, static_cast<size_t>(h->ws.F) * vtd::TP_MAXC, static_cast<size_t>(h->ws.F) * vtd::TP_MAXM);
     if (r != VOFOD_OK)
       return r;
-    // A submitted batch runs its tail on the handle's tail stream: one wave per frame does the flood fills (latency bound,
-    // ~0.1 ms), which overlaps with the streaming kernels of the next batch instead of delaying them.  The tail stream also
-    // serialises the tails of the batches in flight on the shared flood-fill buffers.
+    // A submitted batch runs its tail on the handle's tail stream: one wave per frame does the flood
+    // fills (latency bound, ~0.1 ms), which overlaps with the streaming kernels of the next batch instead of delaying them.
+    // The tail stream also serialises the tails of the batches in flight on the shared flood-fill buffers.
     hipStream_t chain_stream = h->stream;
     struct TailStream
     {
@@ -1931,6 +1931,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     } tail_guard{h, h->stream};
     if (!h->ev_explore)
       HIPCHK(hipEventCreateWithFlags(&h->ev_explore, hipEventDisableTiming));
+    // (per-ticket flood-fill buffers with the tails on the tickets' own streams were tried for small batches in round 3: the
+    // rate of 32-frame batches did not move - 131 k vs 130 k frames/s - so the tails keep taking turns on one stream)
     if (phase == FRAMES_LAUNCH && h->stream_tail)
     {
       HIPCHK(hipEventRecord(ws.ev_packed, chain_stream));  // the cluster tables of this batch are complete
@@ -1939,7 +1941,6 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     }
     else
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_explore, 0));  // (a synchronous call: wait for the tails of batches in flight)
-    ExploreBufs& eb = h->explore;
     vtd::TailParams tp{};
     tp.min_points = dp.classification__min_points;
     tp.max_distance = dp.classification__max_distance;
@@ -1960,7 +1961,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
             eb.d_ovl_count, eb.d_results, eb.d_visited);
     // the records (135 KB) go straight into the pinned host slots from k_tail_finish: no copy command on any stream (see there)
     KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets, ws.h_dets_dev);
-    HIPCHK(hipEventRecord(h->ev_explore, h->stream));
+    HIPCHK(hipEventRecord(h->ev_explore, h->stream));  // the shared flood-fill buffers are free again
     tail_stream_used = h->stream;
   }
   else if (ws.lite)
@@ -2317,7 +2318,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     any_host |= T.host_fallback;
   if (!jobs.empty() && !any_host)
   {
-    r = ensure_explore(h, h->ws.F, jobs.size(), job_members.size() / 3);
+    r = ensure_explore(h, h->explore, h->ws.F, jobs.size(), job_members.size() / 3);
     if (r != VOFOD_OK)
       return r;
     // a collected async batch runs its tail on a second stream so that it does not queue behind the next batch's chain
