@@ -433,7 +433,8 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_key1<false>": 12.0 * n_pts * F,
         "k_key2<true>": 12.0 * n_pts * F,    # brick codes: the second read of the same columns (counted again here, once in the path total)
         "k_key2<false>": 12.0 * n_pts * F,
-        "k_frame_lds": 40.0 * V * F,         # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
+        "k_frame_lds<false>": 40.0 * V * F,  # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
+        "k_frame_lds<true>": 40.0 * V * F,
         # general path (single scans, fallbacks)
         "k_setbits": 12.0 * n_pts * F,
         "k_key": 12.0 * n_pts * F,
@@ -466,18 +467,18 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
     dom = max(path, key=lambda p: kernels[p]["avg_us"])
     dk = kernels[dom]
     # HBM traffic of the dominant kernel from the PMC passes of this same command (tools/run_profiles.sh ->
-    # profiles/r02_traffic.json, corrected per MI355X_MICROARCH.md).  The file records the hash of the kernel sources it was
+    # profiles/rNN_traffic.json, corrected per MI355X_MICROARCH.md).  The file records the hash of the kernel sources it was
     # measured on: a number from other sources would be stale and is not reported.
     traffic, traffic_note = None, "no PMC summary for these kernel sources (run tools/run_profiles.sh)"
-    tr_file = ROOT / "profiles" / "r02_traffic.json"
-    if tr_file.exists():
+    for tr_file in sorted((ROOT / "profiles").glob("r*_traffic.json"), reverse=True):  # the newest round's summary first
         tr = json.loads(tr_file.read_text())
         if tr.get("kernel_source_sha") == kernel_source_sha():
-            if dom in tr:
-                traffic = tr[dom]["hbm_bytes_per_launch_corrected"]
-                traffic_note = "profiles/r02_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, same command)"
-        else:
-            traffic_note = "profiles/r02_traffic.json was measured on other kernel sources: stale, not reported"
+            key = dom if dom in tr else dom.split("<")[0]  # (the summary drops non-numeric template arguments)
+            if key in tr:
+                traffic = tr[key]["hbm_bytes_per_launch_corrected"]
+                traffic_note = f"profiles/{tr_file.name} (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, same command, same kernel sources)"
+            break
+        traffic_note = f"profiles/{tr_file.name} was measured on other kernel sources: stale, not reported"
     roofline = {
         "bound": "hbm",
         "kernel": dom,

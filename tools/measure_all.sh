@@ -3,7 +3,7 @@
 # profiles/<tag>_traffic.json for the kernel sources at hand), then the bench line (which picks the PMC traffic up), then
 # the other configurations.  Everything judged is also copied under gpurun_out/<tag>_summary/ - the only directory that
 # comes back from the box; copy it into profiles/ afterwards.
-TAG=${1:-r02}
+TAG=${1:-r03}
 set -o pipefail
 mkdir -p gpurun_out/${TAG}_summary
 tools/run_profiles.sh ${TAG} > gpurun_out/${TAG}_profiles.log 2>&1; tail -2 gpurun_out/${TAG}_profiles.log

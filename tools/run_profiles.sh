@@ -3,7 +3,7 @@
 # Raw output goes to gpurun_out/ (scratch); tools/summarize_profiles.py reduces it into profiles/ (committed).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
