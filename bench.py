@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--cpu-baseline-scans", type=int, default=512, help="scans timed through the CPU oracle (0 disables); ~10 s of single-thread CPU work")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--host-input-steps", type=int, default=12, help="steps of the host-resident input leg (pinned host columns, VOFOD_MEM_HOST: the nodelet's operating point); 0 disables")
-    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (1..4); their kernel chains run on streams of their own and overlap on the device")
+    ap.add_argument("--inflight", type=int, default=4, help="batches in flight (1..4; four keep the submission of batch k+1 off the wait for the tail of batch k-2: +3 % over three); their kernel chains run on streams of their own and overlap on the device")
     ap.add_argument("--collective", choices=("torch", "cabi"), default="torch", help="N > 1: all-gather through torch.distributed (RCCL / gloo) or through the product's C-ABI (vofod_allgather_detections: RCCL from libvofod_hip.so)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
