@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels_voxelize.h"
 
 namespace vr
@@ -115,18 +117,33 @@ __global__ __launch_bounds__(256) void k_raycast(const RayParams rp, const MapGe
         active = prev < length;
       }
     }
-    int end;
-    const bool head = run_heads(key, lane, end);
-#pragma unroll
-    for (int s2 = 1; s2 < 64; s2 <<= 1)
+    // Runs of lanes in one voxel: segmented inclusive sum with DPP moves (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: vector ALU
+    // only, no LDS crossbar; round 3: 229 -> 220 us).  The last lane of a run holds its total and issues the atomic.
+    // (What bounds the kernel is neither the shuffles nor the atomics - leaving the first 5 m of every ray out of the
+    // accumulation changed 229 to 209 us - but the walk itself: ~130 instructions per DDA step, up to ~140 steps, and only
+    // 2 048 waves for 1 024 SIMDs: two waves per SIMD cannot hide each other's dependent chains.)
+    const uint32_t kprev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(~key), static_cast<int>(key), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    const bool head = lane == 0 || kprev != key;
+    uint32_t f = head ? 1u : 0u;
+    float run = dd;
+    auto segstep = [&](auto ctrl_tag, auto mask_tag) {
+      constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+      const float t = __uint_as_float(dpp_mov0<CTRL, MASK>(__float_as_uint(run)));
+      const uint32_t ft = dpp_mov0<CTRL, MASK>(f);
+      run = f ? run : __fadd_rn(run, t);
+      f |= ft;
+    };
+    segstep(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    segstep(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    segstep(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    segstep(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    segstep(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    segstep(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    const unsigned long long H = __ballot(head);
+    const bool tail = lane == 63 || ((H >> (lane + 1)) & 1ull);
+    if (tail && key != 0xffffffffu)
     {
-      const float t = __shfl_down(dd, s2);
-      if (lane + s2 < end)
-        dd += t;
-    }
-    if (head && key != 0xffffffffu)
-    {
-      unsafeAtomicAdd(&ray[key], dd);
+      unsafeAtomicAdd(&ray[key], run);
       any = true;
     }
   }
