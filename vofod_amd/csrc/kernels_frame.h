@@ -7,8 +7,8 @@
 // So voxelisation (voxel_grid_weighted.cpp:122-188) runs brick-first and the clustering (vofod_nodelet.cpp:689-698)
 // continues on the very same LDS image:
 //   k_key2      one pass over the input columns: crops + transform (vofod_nodelet.cpp:625-655), cell of every
-//               surviving point (voxel_grid_weighted.cpp:131-136) as a *brick code* (brick id * 64 + bit inside the
-//               brick), appended in point order (8 consecutive points per thread: points of one ring that fall into
+//               surviving point (voxel_grid_weighted.cpp:131-136) as a *brick code* (brick coordinates 9 + 9 + 6 bits, then
+//               the bit inside the brick: 6 bits), appended in point order (8 consecutive points per thread: points of one ring that fall into
 //               one voxel / brick stay neighbours in the list);
 //   k_frame_lds 1  brick bitmap of the frame (one LDS atomic per run of codes in the same brick),
 //               2  popcount prefix: a brick's node index = its rank among the occupied bricks,
@@ -114,7 +114,6 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key2(const FrameArgs* args, co
     }
   }
   const int dx = h.div_b[0], dy = h.div_b[1], dz = h.div_b[2];
-  const int nbx = (dx + 3) >> 2, nby = (dy + 3) >> 2;
   uint32_t code[KEY2_PPT];
   uint32_t cnt = 0;
 #pragma unroll
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(KEY2_THREADS) void k_key2(const FrameArgs* args, co
           key_to_ijk(h, key, k0, k1, k2);
       }
       if (ok)
-        code[j] = (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
+        code[j] = ((static_cast<uint32_t>(k0 >> 2) | (static_cast<uint32_t>(k1 >> 2) << 9) | (static_cast<uint32_t>(k2 >> 2) << 18)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));  // as cell_code of k_frame_lds
     }
     cnt += code[j] != FR_CODE_NONE;
   }
@@ -621,6 +620,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   const uint32_t FRAME = SLABS ? n_src + blockIdx.x : blockIdx.x;    // the slot everything is written to
   FrameHdr& h = hdrs[FRAME];
   __shared__ int s_slab[3];  // (slab mode) lattice rows [y0, y1) this workgroup owns, y1h: end of its halo
+  __shared__ int s_mapk[4];  // lattice cell -> map cell offsets, [3]: valid (see below)
   if (rl.on)
   {
     // single-pass input: the frame's lattice (voxel_grid_weighted.cpp:61-113) is set up here, from the bounding box k_key1
@@ -705,6 +705,33 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   const int dv0 = h.div_b[0], dv1 = h.div_b[1], dv2 = h.div_b[2];  // (the header lives in global memory: keep the lattice in registers)
   const uint32_t n_cells = h.n_cells;
   const float hoff0 = h.offset[0], hoff1 = h.offset[1], hoff2 = h.offset[2];
+  if (tid == 0)
+  {
+    // Is the frame's lattice the map's lattice shifted by whole voxels?  (It is whenever the grid is aligned to the map, which
+    // vofod_nodelet.cpp:664 always does.)  The float expression hasCloseTo's caller evaluates - floor((centre - map offset) / vs) -
+    // is then cell + K for every cell: checked at both ends of every axis with the expression itself, the fractional part
+    // far from a cell boundary (the expression's rounding error grows by ~1e-7 per cell).
+    const int dvs[3] = {dv0, dv1, dv2};
+    const float hoffs[3] = {hoff0, hoff1, hoff2};
+    int ok = 1;
+    for (int a = 0; a < 3; a++)
+    {
+      int K = 0;
+      for (int e = 0; e < 2; e++)
+      {
+        const int k = e == 0 ? 0 : dvs[a] - 1;
+        const float c = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k), 0.5f), g.leaf[a]), hoffs[a]);
+        const float t = __fmul_rn(__fsub_rn(c, mg.off[a]), mg.vs_inv);
+        const float fl = floorf(t), fr = t - fl;
+        const int Ke = static_cast<int>(fl) - k;
+        if (e == 0)
+          K = Ke;
+        ok &= (Ke == K) && fr > 0.25f && fr < 0.75f;
+      }
+      s_mapk[a] = K;
+    }
+    s_mapk[3] = ok;
+  }
   auto cell_code = [&](int k0, int k1, int k2) -> uint32_t {
     // one unsigned compare per axis: negative values wrap above every lattice size
     if (static_cast<uint32_t>(k0) >= static_cast<uint32_t>(dv0) || static_cast<uint32_t>(k1) >= static_cast<uint32_t>(dv1) || static_cast<uint32_t>(k2) >= static_cast<uint32_t>(dv2))
@@ -717,8 +744,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       k1 = static_cast<int>(rem / static_cast<uint32_t>(dx));
       k0 = static_cast<int>(rem - static_cast<uint32_t>(k1) * dx);
     }
-    return (static_cast<uint32_t>(((k2 >> 2) * nby + (k1 >> 2)) * nbx + (k0 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
+    // brick coordinates packed like a node descriptor (fr_pack), then the bit inside the brick: no division is needed to get
+    // the coordinates back when the brick becomes a node (pass 3a)
+    return (fr_pack(static_cast<uint32_t>(k0 >> 2), static_cast<uint32_t>(k1 >> 2), static_cast<uint32_t>(k2 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
   };
+  // bit of a packed brick in the frame's brick bitmap
+  auto brick_lin = [&](uint32_t p) -> uint32_t { return (((p >> 18) & 63u) * static_cast<uint32_t>(nby) + ((p >> 9) & 511u)) * static_cast<uint32_t>(nbx) + (p & 511u); };
   // whole cells between the reference lattice and this frame's: both offsets are floats, their difference times inv lies
   // within eps of an integer
   int shift[3] = {0, 0, 0};
@@ -751,8 +782,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         // (the row of the cell the code stands for: an aliased cell is judged by its aliased row)
         if (cd != FR_CODE_NONE)
         {
-          const uint32_t b = cd >> 6;
-          const int row = static_cast<int>(4u * ((b / static_cast<uint32_t>(nbx)) % static_cast<uint32_t>(nby)) + ((cd >> 2) & 3u));
+          const int row = static_cast<int>(4u * ((cd >> 15) & 511u) + ((cd >> 2) & 3u));
           if (row < lo || row >= hi)
             cd = FR_CODE_NONE;
         }
@@ -762,7 +792,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       else
         codes_w[dst0 + i] = cd;
       if (cd != FR_CODE_NONE)
-        atomicOr(&s_bits[cd >> 11], 1u << ((cd >> 6) & 31u));
+      {
+        const uint32_t L = brick_lin(cd >> 6);
+        atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+      }
     }
   };
   if constexpr (!SLABS)
@@ -843,12 +876,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         if (b != cur)
         {
           if (cur != FR_CODE_NONE)
-            atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+          {
+            const uint32_t L = brick_lin(cur);
+            atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+          }
           cur = b;
         }
       }
       if (cur != FR_CODE_NONE)
-        atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+      {
+        const uint32_t L = brick_lin(cur);
+        atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+      }
       n_out += total;
     }
     if (tid == 0)
@@ -923,12 +962,18 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         if (b != cur)
         {
           if (cur != FR_CODE_NONE)
-            atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+          {
+            const uint32_t L = brick_lin(cur);
+            atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+          }
           cur = b;
         }
       }
       if (cur != FR_CODE_NONE)
-        atomicOr(&s_bits[cur >> 5], 1u << (cur & 31u));
+      {
+        const uint32_t L = brick_lin(cur);
+        atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+      }
 #pragma unroll
       for (int u = 0; u < KPT; u++)
         c[u] = cn[u];
@@ -1014,11 +1059,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           if (cur != FR_CODE_NONE)
             flush();
           cur = b;
-          cur_node = fr_node(s_bits64, s_pre, b);
-          const uint32_t bz = b / static_cast<uint32_t>(nbx * nby);
-          const uint32_t brem = b - bz * static_cast<uint32_t>(nbx * nby);
-          const uint32_t by = brem / static_cast<uint32_t>(nbx);
-          s_xyz[cur_node] = fr_pack(brem - by * nbx, by, bz);  // every run of the brick writes the same value
+          cur_node = fr_node(s_bits64, s_pre, brick_lin(b));
+          s_xyz[cur_node] = b;  // the code carries the brick's packed coordinates; every run of the brick writes the same value
           acc = 0ull;
         }
         acc |= 1ull << (c[u] & 63u);
@@ -1251,9 +1293,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     const uint32_t nq = 4u * static_cast<uint32_t>(nby) * nbz;
     const uint32_t qpt = (nq + FR_THREADS - 1) / FR_THREADS;  // <= 32
     const uint32_t q0 = tid * qpt, q1 = min(q0 + qpt, nq);
-    auto row_sum = [&](uint32_t q, uint32_t& r_out, uint32_t& zz_out) -> uint32_t {
-      const uint32_t plane = q / static_cast<uint32_t>(nby);
-      const uint32_t by = q - plane * nby, bz = plane >> 2, zz = plane & 3u;
+    // (plane, brick row) of a thread's first group by one division, then stepped; the sums of its first groups stay in
+    // registers between the two loops (each costs two bitmap look-ups in global memory)
+    auto row_sum = [&](uint32_t plane, uint32_t by, uint32_t& r_out, uint32_t& zz_out) -> uint32_t {
+      const uint32_t bz = plane >> 2, zz = plane & 3u;
       const uint32_t r = bz * nby + by;
       r_out = r;
       zz_out = zz;
@@ -1267,12 +1310,39 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const uint32_t n1 = b1 < nb_total ? fr_node(pk_bits, pk_pre, b1) : n;
       return n1 != n0 ? fr_hsum16(rowT[static_cast<size_t>(r) * 4 + zz]) : 0xffffffffu;  // 0xffffffff: the brick row is empty
     };
+    constexpr int QC = 8;
+    uint32_t cache[QC];
+    const uint32_t plane0 = q0 / static_cast<uint32_t>(nby), by0 = q0 - plane0 * nby;
     uint32_t sum = 0;
-    for (uint32_t q = q0; q < q1; q++)
     {
-      uint32_t r, zz;
-      const uint32_t s = row_sum(q, r, zz);
-      sum += s == 0xffffffffu ? 0u : s;
+      uint32_t plane = plane0, by = by0;
+#pragma unroll
+      for (int j = 0; j < QC; j++)
+      {
+        cache[j] = 0xffffffffu;
+        if (q0 + j < q1)
+        {
+          uint32_t r, zz;
+          cache[j] = row_sum(plane, by, r, zz);
+          sum += cache[j] == 0xffffffffu ? 0u : cache[j];
+          if (++by == static_cast<uint32_t>(nby))
+          {
+            by = 0;
+            plane++;
+          }
+        }
+      }
+      for (uint32_t q = q0 + QC; q < q1; q++)
+      {
+        uint32_t r, zz;
+        const uint32_t sv = row_sum(plane, by, r, zz);
+        sum += sv == 0xffffffffu ? 0u : sv;
+        if (++by == static_cast<uint32_t>(nby))
+        {
+          by = 0;
+          plane++;
+        }
+      }
     }
     const uint32_t incl = wave_incl_scan(sum);
     if (lane == 63)
@@ -1284,24 +1354,41 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const uint32_t x = s_wsum[w];
       run += w < wave ? x : 0u;
     }
-    for (uint32_t q = q0; q < q1; q++)
     {
-      uint32_t r, zz;
-      const uint32_t s = row_sum(q, r, zz);
-      if constexpr (SLABS)
+      uint32_t plane = plane0, by = by0;
+      auto place = [&](uint32_t sv, uint32_t r, uint32_t zz) {
+        if constexpr (SLABS)
+        {
+          // rank of the first voxel of every z plane, and of the plane's first voxel behind the slab's own rows (its halo)
+          uint32_t* planes = fs.planes + static_cast<size_t>(FRAME) * 3 * FR_PLANES;
+          if (by == 0)
+            planes[plane] = run;
+          if (by == static_cast<uint32_t>(s_slab[1] >> 2))
+            planes[FR_PLANES + plane] = run;
+        }
+        if (sv != 0xffffffffu)
+        {
+          rowQ[static_cast<size_t>(r) * 4 + zz] = run;
+          run += sv;
+        }
+        if (++by == static_cast<uint32_t>(nby))
+        {
+          by = 0;
+          plane++;
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < QC; j++)
+        if (q0 + j < q1)
+        {
+          const uint32_t bz = plane >> 2, zz = plane & 3u;
+          place(cache[j], bz * nby + by, zz);
+        }
+      for (uint32_t q = q0 + QC; q < q1; q++)
       {
-        // rank of the first voxel of every z plane, and of the plane's first voxel behind the slab's own rows (its halo)
-        const uint32_t plane = q / static_cast<uint32_t>(nby), by = q - plane * nby;
-        uint32_t* planes = fs.planes + static_cast<size_t>(FRAME) * 3 * FR_PLANES;
-        if (by == 0)
-          planes[plane] = run;
-        if (by == static_cast<uint32_t>(s_slab[1] >> 2))
-          planes[FR_PLANES + plane] = run;
-      }
-      if (s != 0xffffffffu)
-      {
-        rowQ[static_cast<size_t>(r) * 4 + zz] = run;
-        run += s;
+        uint32_t r, zz;
+        const uint32_t sv = row_sum(plane, by, r, zz);
+        place(sv, r, zz);
       }
     }
   }
@@ -1993,12 +2080,24 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
             continue;
           const int p = __ffsll(static_cast<long long>(a)) - 1;
           a &= a - 1;
-          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), hoff0);
-          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), hoff1);
-          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), hoff2);
-          const int mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
-          const int my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
-          const int mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
+          int mx_, my_, mz_;
+          if (s_mapk[3])
+          {
+            // the lattice is a translate of the map's by whole voxels (checked in the prologue): the map cell of a voxel
+            // centre is its lattice cell plus a constant - integer adds instead of three float expressions per voxel
+            mx_ = 4 * bx + (p & 3) + s_mapk[0];
+            my_ = 4 * by + ((p >> 2) & 3) + s_mapk[1];
+            mz_ = 4 * bz + (p >> 4) + s_mapk[2];
+          }
+          else
+          {
+            const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), hoff0);
+            const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), hoff1);
+            const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), hoff2);
+            mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
+            my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
+            mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
+          }
           if (mx_ >= 0 && mx_ < mg.sx && my_ >= 0 && my_ < mg.sy && mz_ >= 0 && mz_ < mg.sz)
             Lq[q] = (static_cast<uint64_t>(mz_) * mg.sy + my_) * mg.sx + mx_;
           else  // a centre outside the map (a point on the far face of the operation area): the clipped stencil sweep
