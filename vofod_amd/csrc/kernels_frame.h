@@ -256,8 +256,10 @@ template <bool PACKED>
 __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
 {
 #pragma clang fp contract(off)
-  uint32_t FRAME, BX, GX;
-  if (!frame_block(g, FRAME, BX, GX))
+  // (2-D grid: blockIdx.y = frame - the frame / block split of a 1-D grid costs two integer divisions per wave, ~7 % of this
+  // kernel's vector instructions; the XCD-aware 1-D mapping of frame_block stays available behind g.xcd_map)
+  uint32_t FRAME = blockIdx.y, BX = blockIdx.x, GX = 0;
+  if (g.xcd_map && !frame_block(g, FRAME, BX, GX))
     return;
   (void)GX;
   const FrameArgs a = args[FRAME];  // (a copy: the transform stays in scalar registers)
@@ -621,6 +623,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   FrameHdr& h = hdrs[FRAME];
   __shared__ int s_slab[3];  // (slab mode) lattice rows [y0, y1) this workgroup owns, y1h: end of its halo
   __shared__ int s_mapk[4];  // lattice cell -> map cell offsets, [3]: valid (see below)
+  __shared__ __attribute__((aligned(16))) uint32_t s_near[5][4];  // descriptors of the stencil rows that hold adjacent bricks (phase D)
+  __shared__ uint32_t s_near_n;
   if (rl.on)
   {
     // single-pass input: the frame's lattice (voxel_grid_weighted.cpp:61-113) is set up here, from the bounding box k_key1
@@ -1575,12 +1579,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     return raw << shw;
   };
   {
-    // the adjacent bricks sit in at most five stencil rows ((dy, dz) in the half stencil with |dy|, |dz| <= 1): lane `sub`
-    // of the eight lanes of a brick serves the sub-th of them for every brick, its descriptor stays in registers
-    const int sub = tid % LB_LANES;
-    int ddy = 0, ddz = 0;
-    uint32_t valid = 0, axis = 0;
-    unsigned long long ov = 0;
+    // the adjacent bricks sit in at most five stencil rows ((dy, dz) in the half stencil with |dy|, |dz| <= 1): work item =
+    // (brick, one of these rows), P consecutive lanes per brick (round 2 gave every brick eight lanes, three of them idle);
+    // the rows' descriptors wait in LDS
+    if (tid == 0)
     {
       int k = 0;
       for (int row = 0; row < n_rows; row++)
@@ -1589,22 +1591,29 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         uint32_t v, ax, nr;
         unsigned long long o;
         load_row(row, y, z, v, ax, nr, o);
-        if (!(v & nr))
+        if (!(v & nr) || k >= 5)
           continue;
-        if (k == sub)
-        {
-          ddy = y;
-          ddz = z;
-          valid = v & nr;
-          axis = ax;
-          ov = o;
-        }
+        s_near[k][0] = (static_cast<uint32_t>(y) & 0xffu) | ((static_cast<uint32_t>(z) & 0xffu) << 8) | (((v & nr) & 0xffu) << 16) | ((ax & 0xffu) << 24);
+        s_near[k][1] = 0u;
+        s_near[k][2] = static_cast<uint32_t>(o);
+        s_near[k][3] = static_cast<uint32_t>(o >> 32);
         k++;
       }
+      s_near_n = static_cast<uint32_t>(k);
     }
-    const uint32_t n_round = (n + FR_THREADS / LB_LANES - 1) / (FR_THREADS / LB_LANES) * (FR_THREADS / LB_LANES);
-    for (uint32_t t = tid / LB_LANES; t < n_round; t += FR_THREADS / LB_LANES)  // wave-uniform trip counts: the reservations below scan the wave
+    __syncthreads();
+    const uint32_t P = max(s_near_n, 1u);
+    const uint32_t Pm = P > 1u ? 0xffffffffu / P + 1u : 0u;  // idx / P == umulhi(idx, ceil(2^32 / P)) for idx < 2^32 / P
+    const uint32_t items = n * P;
+    const uint32_t n_round = (items + FR_THREADS - 1) / FR_THREADS * FR_THREADS;
+    for (uint32_t idx = tid; idx < n_round; idx += FR_THREADS)  // wave-uniform trip counts: the reservations below scan the wave
     {
+      const uint32_t t = P > 1u ? __umulhi(idx, Pm) : idx;
+      const uint32_t sub = idx - t * P;
+      const uint4 dsc = *reinterpret_cast<const uint4*>(&s_near[min(sub, 4u)][0]);
+      const int ddy = static_cast<int8_t>(dsc.x & 0xffu), ddz = static_cast<int8_t>((dsc.x >> 8) & 0xffu);
+      const uint32_t valid = s_near_n ? (dsc.x >> 16) & 0xffu : 0u, axis = dsc.x >> 24;
+      const unsigned long long ov = static_cast<unsigned long long>(dsc.z) | (static_cast<unsigned long long>(dsc.w) << 32);
       const bool live = t < n;
       const uint32_t xyz = live ? s_xyz[t] : 0u;
       const int bx = fr_bx(xyz), ny = fr_by(xyz) + ddy, nz = fr_bz(xyz) + ddz;

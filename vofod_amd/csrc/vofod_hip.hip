@@ -1045,10 +1045,11 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     // one pass over the input: bounding box + reference cells (k_key1), then the frames' lattices
     // (k_init_hdr has cleared the frames' list counters; one workgroup per KEY1_THREADS * KEY1_PPT points, no stride loop)
     const uint32_t gk1 = std::max(1u, (max_pts + KEY1_THREADS * KEY1_PPT - 1) / (KEY1_THREADS * KEY1_PPT));
+    const dim3 gk = g.xcd_map ? fgrid(g, gk1) : dim3(gk1, n);  // (blockIdx.y = frame: see k_key1)
     if (packed)
-      KLAUNCH(h, k_key1<true>, fgrid(g, gk1), dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
+      KLAUNCH(h, k_key1<true>, gk, dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
     else
-      KLAUNCH(h, k_key1<false>, fgrid(g, gk1), dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
+      KLAUNCH(h, k_key1<false>, gk, dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
   }
   else
     KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
