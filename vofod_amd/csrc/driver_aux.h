@@ -698,6 +698,8 @@ void vofod_destroy(vofod_handle* h)
     (void)hipStreamDestroy(h->stream_key);
   if (h->stream_frame)
     (void)hipStreamDestroy(h->stream_frame);
+  if (h->stream_frame2)
+    (void)hipStreamDestroy(h->stream_frame2);
   for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
     if (h->chain_stream[t])
       (void)hipStreamDestroy(h->chain_stream[t]);
@@ -742,6 +744,7 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
     // staged pipeline of submitted batches (process_frames): streaming kernels below the frame kernels
     CREATE_CHK(hipStreamCreateWithPriority(&h->stream_key, hipStreamNonBlocking, prio_lo));
     CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frame, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frame2, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
   }
   h->chain_stream[0] = h->stream;
   for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)

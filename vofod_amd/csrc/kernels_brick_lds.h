@@ -123,7 +123,10 @@ __device__ __forceinline__ bool lb_pair_conn(const LbTables& tab, const GridPara
         const float pzc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + pz), 0.5f), g.leaf[2]), h.offset[2]);
         const float qyc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * (by + ddy) + qy), 0.5f), g.leaf[1]), h.offset[1]);
         const float qzc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * (bz + ddz) + qz), 0.5f), g.leaf[2]), h.offset[2]);
+        // (rare path - boundary cases of the tolerance only: kept rolled, it set the kernel's register peak when unrolled)
+#pragma unroll 1
         for (int px = 0; px < 4; px++)
+#pragma unroll 1
           for (int qx = 0; qx < 4; qx++)
           {
             if (!((a4 >> px) & 1u) || !((b4 >> qx) & 1u))

@@ -33,6 +33,10 @@ namespace vk
 {
 
 constexpr int FR_THREADS = 1024;
+#ifndef FR_WRITE_BACK_DEF
+#define FR_WRITE_BACK_DEF 1
+#endif
+constexpr bool FR_WRITE_BACK = FR_WRITE_BACK_DEF != 0;  // pass 1 writes the converted codes back (0: pass 3a converts again)
 constexpr int FR_BW64 = LB_BITWORDS / 2;  // 64-bit words of the brick-lattice bitmap
 #ifndef FR_WAVE_PRIO
 #define FR_WAVE_PRIO 3
@@ -192,6 +196,9 @@ struct RefLattice
   int32_t on;
 };
 
+#ifndef KEY1_CMP_TEST
+#define KEY1_CMP_TEST 0
+#endif
 #ifndef KEY1_THREADS_DEF
 #define KEY1_THREADS_DEF 256
 #endif
@@ -305,12 +312,19 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
   // Branch-free per point: a value lies inside a closed interval iff the median of (value, low, high) is the value itself -
   // one v_med3 + one compare per axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed
   // point, which fails the operation-area test: the explicit isfinite() of the first crop is implied.
+#if KEY1_CMP_TEST
+  // (two compares per axis, bounds read from scalar registers: six vector registers fewer than the v_med3 form - what it takes
+  // to bring the kernel's allocation to 48 registers, so that TWO of its waves fit beside a frame workgroup per SIMD)
+  auto inside = [](float v, float lo, float hi) { return static_cast<int>(v >= lo) & static_cast<int>(v <= hi); };
+  const float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
+#else
   auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
   // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop)
   float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
 #pragma unroll
   for (int c = 0; c < 3; c++)
     asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
+#endif
   const float solid_lim = 0.5f - rl.eps;
   const float qnan = __int_as_float(0x7fc00000);
 #pragma unroll
@@ -942,18 +956,21 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         for (int u = 0; u < KPT; u++)
           if (base + u < n_pass1)
             c[u] = ref_code(c[u]);
-        if (vec_ok && base + KPT <= n_pass1)
+        if constexpr (FR_WRITE_BACK)
         {
+          if (vec_ok && base + KPT <= n_pass1)
+          {
 #pragma unroll
-          for (int q = 0; q < KPT / 4; q++)
-            *reinterpret_cast<uint4*>(codes_w + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
-        }
-        else
-        {
+            for (int q = 0; q < KPT / 4; q++)
+              *reinterpret_cast<uint4*>(codes_w + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+          }
+          else
+          {
 #pragma unroll
-          for (int u = 0; u < KPT; u++)
-            if (base + u < n_pass1)
-              codes_w[base + u] = c[u];
+            for (int u = 0; u < KPT; u++)
+              if (base + u < n_pass1)
+                codes_w[base + u] = c[u];
+          }
         }
       }
       uint32_t cur = FR_CODE_NONE;
@@ -1042,6 +1059,16 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     {
       if (base + FR_THREADS * KPT < n_keys)
         load_codes(base + FR_THREADS * KPT, cn);
+      if constexpr (!FR_WRITE_BACK && !SLABS)
+      {
+        if (rl.on)  // pass 1 kept the reference cells in the list (the fragile points' codes behind them are brick codes already)
+        {
+#pragma unroll
+          for (int u = 0; u < KPT; u++)
+            if (base + u < n_ref)
+              c[u] = ref_code(c[u]);
+        }
+      }
       uint32_t cur = FR_CODE_NONE, cur_node = 0;
       unsigned long long acc = 0ull;
       auto flush = [&]() {

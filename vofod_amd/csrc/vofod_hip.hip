@@ -491,6 +491,8 @@ struct vofod_handle
   hipStream_t stream_tail = nullptr;  // tail (k_explore) of collected async batches
   hipStream_t stream_key = nullptr;   // staged pipeline: streaming kernels of all submitted batches, lowest priority
   hipStream_t stream_frame = nullptr; // staged pipeline: frame kernels of all submitted batches
+  hipStream_t stream_frame2 = nullptr; // frame kernels alternate between the two frame streams
+  int frame_toggle = 0;
   // Batches in flight (more than the four hardware queues the runtime maps streams onto gain nothing: eight 32-frame batches
   // in flight measured 121 k frames/s against 132 k with three).  Slots are allocated on first use.
   static constexpr int MAX_INFLIGHT = 4;
@@ -1851,7 +1853,13 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   if (staged)
   {
     HIPCHK(hipEventRecord(ws.ev_key, h->stream));
-    h->stream = h->stream_frame;
+    // Consecutive frame kernels alternate between two streams: frame kernel k+1 waits neither for the LAST workgroup of frame
+    // kernel k (its workgroups take the CUs as those of k retire: frames last 260-350 us) nor for the 14 us launch hand-off
+    // behind it.  Measured +2..4 % (541 / 533 / 533 k against 519 / 510 / 534 k frames/s, alternating runs on one box); the
+    // pipeline's pace is then set by k_key1, which runs as a guest of the frame kernels all the time (one wave per SIMD beside a
+    // frame workgroup: ~440 us per batch).  VOFOD_FRAME_STREAMS=1: one frame stream.
+    static const bool two_frame_streams = !(std::getenv("VOFOD_FRAME_STREAMS") && std::atoi(std::getenv("VOFOD_FRAME_STREAMS")) == 1);
+    h->stream = (two_frame_streams && h->stream_frame2 && (h->frame_toggle ^= 1)) ? h->stream_frame2 : h->stream_frame;
     HIPCHK(hipStreamWaitEvent(h->stream, ws.ev_key, 0));
   }
 
