@@ -571,6 +571,47 @@ def test_pipelined_batches_equal_synchronous(oracle, hip):
     with pytest.raises(Exception):
         dev.batch_collect(0)
 
+def test_host_batch_in_one_block_and_params_changed_in_flight(oracle, hip):
+    """(1) A host-resident batch whose frames are packed x | y | z columns at a constant pitch (one block) is moved by ONE 2-D
+    copy (process_frames' staging): same results as the same scans given as separate arrays.  (2) vofod_set_dynamic_params
+    between submit and collect: the submitted batch is classified with the parameters of its submission."""
+    F = 6
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=F)
+    scene = synth.make_scene(21, n_targets=3)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+        for sc in synth.scan_sequence(scene, "os1-128", 5, seed0=300):
+            d.process_scan(sc.scan, sc.tf, flags=capi.SCAN_AUTO_RAYCAST)
+    sync_maps(ref, dev)
+    base = synth.scan_sequence(scene, "os1-128", F, seed0=310)
+    h, w, _, _ = synth.SENSORS["os1-128"]
+    n = h * w
+    # columns of one frame follow each other directly, frames at a constant pitch with padding between them: x | y | z | pad
+    flat = np.zeros((F, 3 * n + 192), dtype=np.float32)
+    for f, sc in enumerate(base):
+        flat[f, :n], flat[f, n : 2 * n], flat[f, 2 * n : 3 * n] = sc.x, sc.y, sc.z
+    in_block = [ScanData(x=flat[f, :n], y=flat[f, n : 2 * n], z=flat[f, 2 * n : 3 * n], width=w, height=h, stride_bytes=4) for f in range(F)]
+    tfs = np.stack([sc.tf for sc in base])
+    want, want_per, want_dbg = ref.process_batch([sc.scan for sc in base], tfs, debug=True)
+    got, got_per, got_dbg = dev.process_batch(in_block, tfs, debug=True)
+    np.testing.assert_array_equal(got_per, want_per)
+    assert_detections_equal(want, got)
+    for x, y in zip(want_dbg, got_dbg):
+        assert_scan_debug_equal(x, y)
+    assert len(want) > 0
+    # (2) parameters changed while the batch is in flight
+    t = dev.batch_submit(in_block, tfs)
+    dev.set_dynamic_params(classification__min_points=10_000, output__position_sigma=123.0)  # would reject every cluster / change every covariance
+    g, per = dev.batch_collect(t)
+    dev.set_dynamic_params(classification__min_points=ref.dp.classification__min_points, output__position_sigma=ref.dp.output__position_sigma)
+    np.testing.assert_array_equal(per, want_per)
+    assert_detections_equal(want, _rebase_ids(g, want))
+    # and a batch submitted under the changed parameters does see them
+    dev.set_dynamic_params(classification__min_points=10_000)
+    g2, per2 = dev.batch_collect(dev.batch_submit(in_block, tfs))
+    assert len(g2) == 0 and not per2.any()
+
 
 def test_collect_with_too_small_an_array_keeps_the_ticket(oracle, hip):
     """vofod_batch_collect with an `out` too small: VOFOD_ERR_CAPACITY, *n_out = the size needed, the ticket stays pending and
