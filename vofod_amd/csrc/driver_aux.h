@@ -359,7 +359,8 @@ int sepclusters_finish_locked(vofod_handle* h)
   ep.n_offsets = static_cast<int>(offs.size() / 3);
   Workspace& ws = h->sepws;
   const uint32_t gv = (ws.vox_cap + 255) / 256;
-  KLAUNCH(h, vr::k_sep_erase, dim3(gv), dim3(256), ep, h->mg, ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure, s.d_offsets, h->d_map);
+  const uint32_t oy = static_cast<uint32_t>(std::max(1, std::min(ep.n_offsets / 16, 256)));
+  KLAUNCH(h, vr::k_sep_erase, dim3(gv, oy), dim3(256), ep, h->mg, ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure, s.d_offsets, h->d_map);
   HIPCHK(hipStreamSynchronize(h->stream));
   h->mapbits_valid = false;
   return VOFOD_OK;

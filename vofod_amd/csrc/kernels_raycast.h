@@ -465,7 +465,9 @@ __global__ __launch_bounds__(256) void k_sep_erase(const EraseParams ep, const M
     return;
   const float4 p = pts[v];
   const int pos[3] = {static_cast<int>(p.x), static_cast<int>(p.y), static_cast<int>(p.z)};  // cast<int>() truncates (:1252)
-  for (int o = 0; o < ep.n_offsets; o++)
+  // (the stencil - thousands of offsets at small voxel sizes - is dealt over blockIdx.y: the voxels of unsure clusters are few,
+  // one thread per voxel walking the whole stencil left the chip empty: 2.4 ms at 0.1 m)
+  for (int o = blockIdx.y; o < ep.n_offsets; o += gridDim.y)
   {
     const int x = pos[0] + offsets[3 * o], y = pos[1] + offsets[3 * o + 1], z = pos[2] + offsets[3 * o + 2];
     if (x < 0 || x >= mg.sx || y < 0 || y >= mg.sy || z < 0 || z >= mg.sz)
