@@ -347,7 +347,7 @@ def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch,
 def _rebase_ids(got, want):
     got = got.copy()
     if len(got) and len(want):
-        got["id"] += want["id"][0] - got["id"][0]
+        got["id"] = (got["id"].astype(np.int64) + (int(want["id"][0]) - int(got["id"][0]))).astype(got["id"].dtype)
     return got
 
 
