@@ -196,9 +196,6 @@ struct RefLattice
   int32_t on;
 };
 
-#ifndef KEY1_CMP_TEST
-#define KEY1_CMP_TEST 0
-#endif
 #ifndef KEY1_THREADS_DEF
 #define KEY1_THREADS_DEF 256
 #endif
@@ -312,19 +309,12 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
   // Branch-free per point: a value lies inside a closed interval iff the median of (value, low, high) is the value itself -
   // one v_med3 + one compare per axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed
   // point, which fails the operation-area test: the explicit isfinite() of the first crop is implied.
-#if KEY1_CMP_TEST
-  // (two compares per axis, bounds read from scalar registers: six vector registers fewer than the v_med3 form - what it takes
-  // to bring the kernel's allocation to 48 registers, so that TWO of its waves fit beside a frame workgroup per SIMD)
-  auto inside = [](float v, float lo, float hi) { return static_cast<int>(v >= lo) & static_cast<int>(v <= hi); };
-  const float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
-#else
   auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
   // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop)
   float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
 #pragma unroll
   for (int c = 0; c < 3; c++)
     asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
-#endif
   const float solid_lim = 0.5f - rl.eps;
   const float qnan = __int_as_float(0x7fc00000);
 #pragma unroll
