@@ -249,6 +249,31 @@ __device__ __forceinline__ float wave_fmax(float v)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// the six wave reductions of a bounding box in one block: the steps of the six independent chains are interleaved, so that no
+// DPP instruction reads a register the instruction before it wrote (the hazard costs two wait states: 42 s_nop when the chains
+// run one after the other)
+__device__ __forceinline__ void wave_bbox(float (&mn)[3], float (&mx)[3])
+{
+#define VOFOD_BBOX_STEP(ctl)                          \
+  "v_min_f32_dpp %0, %0, %0 " ctl "\n\t"              \
+  "v_min_f32_dpp %1, %1, %1 " ctl "\n\t"              \
+  "v_min_f32_dpp %2, %2, %2 " ctl "\n\t"              \
+  "v_max_f32_dpp %3, %3, %3 " ctl "\n\t"              \
+  "v_max_f32_dpp %4, %4, %4 " ctl "\n\t"              \
+  "v_max_f32_dpp %5, %5, %5 " ctl "\n\t"
+  asm("s_nop 1\n\t" VOFOD_BBOX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") VOFOD_BBOX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+          VOFOD_BBOX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") VOFOD_BBOX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+              VOFOD_BBOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") VOFOD_BBOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+      : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]));
+#undef VOFOD_BBOX_STEP
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+  {
+    mn[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn[c]), 63));
+    mx[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx[c]), 63));
+  }
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Round 3: the kernel was bound by its vector instructions (~112 executed per point).  Now: the transform and the cell
@@ -378,12 +403,13 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
   // bounding box of the block ...
   const bool any_kept = (cnt | frag_mask) != 0u;
   int mn[3], mx[3];
+  wave_bbox(fmn, fmx);
 #pragma unroll
   for (int c = 0; c < 3; c++)
   {
     // (+-inf where the wave kept nothing: the ordered form of +inf / -inf is the identity of the integer atomics below)
-    mn[c] = f2ord(wave_fmin(fmn[c]));
-    mx[c] = f2ord(wave_fmax(fmx[c]));
+    mn[c] = f2ord(fmn[c]);
+    mx[c] = f2ord(fmx[c]);
   }
   (void)any_kept;
   __shared__ int s_red[KEY1_THREADS / 64][6];
