@@ -26,6 +26,11 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# The library keeps up to a dozen HIP streams busy (key / frame / tail stages, one chain per small batch in flight); the
+# runtime deals streams onto FOUR hardware queues by default, and streams that share a queue take turns.  Read by the runtime
+# when it initialises, i.e. before the first HIP call of the process; spawned ranks inherit it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
@@ -42,7 +47,7 @@ def parse():
     ap.add_argument("--cpu-baseline-scans", type=int, default=512, help="scans timed through the CPU oracle (0 disables); ~10 s of single-thread CPU work")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--host-input-steps", type=int, default=12, help="steps of the host-resident input leg (pinned host columns, VOFOD_MEM_HOST: the nodelet's operating point); 0 disables")
-    ap.add_argument("--inflight", type=int, default=4, help="batches in flight (1..4; four keep the submission of batch k+1 off the wait for the tail of batch k-2: +3 % over three); their kernel chains run on streams of their own and overlap on the device")
+    ap.add_argument("--inflight", type=int, default=4, help="batches in flight (1..8; four keep the submission of batch k+1 off the wait for the tail of batch k-2: +3 %% over three; more gain nothing at 256 frames); their kernel chains run on streams of their own and overlap on the device")
     ap.add_argument("--collective", choices=("torch", "cabi"), default="torch", help="N > 1: all-gather through torch.distributed (RCCL / gloo) or through the product's C-ABI (vofod_allgather_detections: RCCL from libvofod_hip.so)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
@@ -318,7 +323,10 @@ def main():
             # configs[3] spreads 256 scans over 8 GPUs: 32 per GPU and step.  The same handle, batches of 32 frames.
             sub, sub_tfs = scans[:32], tfs[:32]
 
-            depth32 = 3  # (eight in flight measured slower than three: the runtime maps the streams onto four hardware queues)
+            # eight in flight: every small batch runs its whole chain, tail included, on its ticket's stream.  (The streams must not
+            # share hardware queues for that: GPU_MAX_HW_QUEUES above.  With the runtime's default of four, eight in flight gave
+            # 142 k frames/s, with sixteen 226-289 k; round 2's three in flight on the shared tail stream: 101-132 k.)
+            depth32 = 8
 
             def run32(k):
                 infl = []
@@ -329,7 +337,7 @@ def main():
                 while infl:
                     det.batch_collect(infl.pop(0))
 
-            run32(5)
+            run32(2 * depth32 + 4)  # (every ticket's workspace and buffers are allocated on first use: all of them before the clock starts)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             run32(100)
@@ -344,7 +352,7 @@ def main():
             k32 = {knames[64 * i : 64 * i + 64].split(b"\0", 1)[0].decode(): round(1e3 * kms[i] / max(kcalls[i], 1), 1) for i in range(kn)}
             out["config3_share"] = {"frames_per_gpu_per_step": 32, "frames_per_s": 32 * 100 / dt32, "ms_per_step": 1e3 * dt32 / 100, "kernel_us": k32,
                                     "batches_in_flight": depth32,
-                                    "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU, three in flight on streams of their own; one workgroup per frame leaves most CUs idle in k_frame_lds"}
+                                    "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU, eight in flight, each on a stream (and hardware queue) of its own with its own tail; a frame kernel of 32 workgroups leaves 7/8 of the CUs to the other batches in flight"}
         if world == 1 and args.host_input_steps > 0:
             out["host_input"] = host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w)
         if not args.no_profile_pass:

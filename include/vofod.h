@@ -266,9 +266,9 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
                         vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out,
                         vofod_scan_debug* dbg);
 
-/* The same, pipelined: submit enqueues the kernels of a batch and returns a ticket (0..3; at most four batches in flight:
+/* The same, pipelined: submit enqueues the kernels of a batch and returns a ticket (0..7; at most eight batches in flight:
  * streaming kernels, frame kernels and classification tails of consecutive batches run as a three-stage pipeline on the
- * device; batches of fewer than 128 frames run side by side on streams of their own), collect waits for it and returns the detections.  Submitting batch k+1 (and k+2) before collecting batch k keeps
+ * device; batches of fewer than 128 frames run side by side on streams of their own, tails included - see INTEGRATION.md on GPU_MAX_HW_QUEUES), collect waits for it and returns the detections.  Submitting batch k+1 (and k+2) before collecting batch k keeps
  * the pipeline full.  Read-only map only (VOFOD_SCAN_NO_MAP_UPDATE semantics); collect in submit order for deterministic
  * detection ids.  The scans' host buffers need not outlive submit.  collect with an `out` too small for the batch returns
  * VOFOD_ERR_CAPACITY with *n_out = the detections to make room for; the ticket then stays pending and no ids are handed out

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from vofod_amd import capi, synth
-from vofod_amd.detector import ScanData, cluster, voxel_grid_counted, voxel_grid_weighted
+from vofod_amd.detector import ScanData, VofodError, cluster, voxel_grid_counted, voxel_grid_weighted
 
 from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair, sync_maps
 
@@ -570,6 +570,38 @@ def test_pipelined_batches_equal_synchronous(oracle, hip):
         assert_detections_equal(wd, gd)
     with pytest.raises(Exception):
         dev.batch_collect(0)
+
+def test_eight_small_batches_in_flight_with_tails_of_their_own(oracle, hip):
+    """Small batches (fewer frames than half the CUs) run their whole chain - classification tail included - on the ticket's
+    stream with flood-fill buffers of their own: eight in flight, collected out of submission order, give the detections of
+    the synchronous calls; a ninth submission is refused with VOFOD_ERR_CAPACITY and leaves the eight intact."""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5, max_batch=6)
+    scene = synth.make_scene(21, n_targets=3)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+        for s in synth.scan_sequence(scene, "os1-128", 5, seed0=300):
+            d.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+    sync_maps(ref, dev)
+    batches = [synth.scan_sequence(scene, "os1-128", 4 + (b % 3), seed0=310 + 10 * b) for b in range(8)]
+    scan_lists = [[s.scan for s in b] for b in batches]
+    tf_lists = [np.stack([s.tf for s in b]) for b in batches]
+    want = [ref.process_batch(sl, tl) for sl, tl in zip(scan_lists, tf_lists)]
+    assert sum(len(w[0]) for w in want) > 0
+    for rounds in range(2):  # the second round reuses every ticket's workspace and buffers
+        tickets = [dev.batch_submit(sl, tl) for sl, tl in zip(scan_lists, tf_lists)]
+        assert sorted(tickets) == list(range(8))
+        with pytest.raises(VofodError) as e:
+            dev.batch_submit(scan_lists[0], tf_lists[0])
+        assert e.value.status == capi.ERR_CAPACITY
+        got = {}
+        for k in (3, 0, 7, 1, 6, 2, 5, 4):
+            got[k] = dev.batch_collect(tickets[k])
+        for k in range(8):
+            (wd, wp), (gd, gp) = want[k], got[k]
+            np.testing.assert_array_equal(gp, wp)
+            assert_detections_equal(wd, _rebase_ids(gd, wd))
+
 
 def test_host_batch_in_one_block_and_params_changed_in_flight(oracle, hip):
     """(1) A host-resident batch whose frames are packed x | y | z columns at a constant pitch (one block) is moved by ONE 2-D

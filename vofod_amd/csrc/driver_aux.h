@@ -670,7 +670,10 @@ void vofod_destroy(vofod_handle* h)
   for (void* p : ptrs)
     if (p)
       (void)hipFree(p);
-  for (ExploreBufs* e : {&h->explore})
+  std::vector<ExploreBufs*> explore_all{&h->explore};
+  for (ExploreBufs& e : h->explore_slot)
+    explore_all.push_back(&e);
+  for (ExploreBufs* e : explore_all)
     for (void* p : {static_cast<void*>(e->d_overlay), static_cast<void*>(e->d_stack), static_cast<void*>(e->d_explored), static_cast<void*>(e->d_touched), static_cast<void*>(e->d_ovl_list),
                     static_cast<void*>(e->d_ovl_count), static_cast<void*>(e->d_job_begin), static_cast<void*>(e->d_visited), static_cast<void*>(e->d_jobs), static_cast<void*>(e->d_results),
                     static_cast<void*>(e->d_members)})
@@ -1086,7 +1089,7 @@ int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tf
       t = i;
   if (t < 0)
   {
-    h->err = "four batches already in flight: collect one first";
+    h->err = "eight batches already in flight: collect one first";
     return VOFOD_ERR_CAPACITY;
   }
   Workspace* w = h->slot(t);

@@ -495,10 +495,11 @@ struct vofod_handle
   int frame_toggle = 0;
   // Batches in flight (more than the four hardware queues the runtime maps streams onto gain nothing: eight 32-frame batches
   // in flight measured 121 k frames/s against 132 k with three).  Slots are allocated on first use.
-  static constexpr int MAX_INFLIGHT = 4;
+  static constexpr int MAX_INFLIGHT = 8;
   hipStream_t chain_stream[MAX_INFLIGHT] = {};  // [0] == stream; in-flight batches run their chains on separate streams and overlap on the device
-  Workspace wsx[MAX_INFLIGHT - 1];              // workspaces of tickets 1..3 (ticket 0 uses ws)
+  Workspace wsx[MAX_INFLIGHT - 1];              // workspaces of tickets 1..7 (ticket 0 uses ws)
   Workspace* slot(int t) { return t == 0 ? &ws : &wsx[t - 1]; }
+  ExploreBufs explore_slot[MAX_INFLIGHT];  // flood-fill buffers of small submitted batches: their tails run on the tickets' own streams
 
   float exclude_center[3], oparea_center[3];
   uint64_t background_min_sufficient_pts = 0;
@@ -1924,8 +1925,20 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     }
     if (h->n_bg_voxels > h->background_min_sufficient_pts)
       h->background_pts_sufficient = true;
-    ExploreBufs& eb = h->explore;
-    r = ensure_explore(h, eb, h->ws.F, static_cast<size_t>(h->ws.F) * vtd::TP_MAXC, static_cast<size_t>(h->ws.F) * vtd::TP_MAXM);
+    // A small submitted batch (fewer frames than half the CUs: its whole chain runs on the ticket's stream) keeps flood-fill
+    // buffers of its own and its tail on that stream: the tails of the batches in flight overlap.  On the shared tail stream
+    // they took turns - k_tail_prep + k_explore + k_tail_finish last 250-280 us in the company of other batches' frame kernels
+    // (120 us alone), and that turn WAS the pace of 32-frame batches (device timeline, tools/trace32.sh).
+    int own_tail = -1;
+    if (phase == FRAMES_LAUNCH && two_chains && !staged && n < 128u)
+      for (int t = 0; t < vofod_handle::MAX_INFLIGHT; t++)
+        if (&ws == h->slot(t))
+          own_tail = t;
+    ExploreBufs& eb = own_tail >= 0 ? h->explore_slot[own_tail] : h->explore;
+    {
+      const uint32_t ebF = own_tail >= 0 ? std::max<uint32_t>(eb.F, (n + 31u) & ~31u) : h->ws.F;
+      r = ensure_explore(h, eb, ebF, static_cast<size_t>(ebF) * vtd::TP_MAXC, static_cast<size_t>(ebF) * vtd::TP_MAXM);
+    }
     if (r != VOFOD_OK)
       return r;
     // A submitted batch runs its tail on the handle's tail stream: one wave per frame does the flood
@@ -1940,9 +1953,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     } tail_guard{h, h->stream};
     if (!h->ev_explore)
       HIPCHK(hipEventCreateWithFlags(&h->ev_explore, hipEventDisableTiming));
-    // (per-ticket flood-fill buffers with the tails on the tickets' own streams were tried for small batches in round 3: the
-    // rate of 32-frame batches did not move - 131 k vs 130 k frames/s - so the tails keep taking turns on one stream)
-    if (phase == FRAMES_LAUNCH && h->stream_tail)
+    // (large batches: the tails take turns on the tail stream, underneath the frame kernel of the next batch)
+    if (own_tail >= 0)
+      ;  // (own buffers, own stream: nothing to wait for)
+    else if (phase == FRAMES_LAUNCH && h->stream_tail)
     {
       HIPCHK(hipEventRecord(ws.ev_packed, chain_stream));  // the cluster tables of this batch are complete
       h->stream = h->stream_tail;
@@ -1970,7 +1984,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
             eb.d_ovl_count, eb.d_results, eb.d_visited);
     // the records (135 KB) go straight into the pinned host slots from k_tail_finish: no copy command on any stream (see there)
     KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets, ws.h_dets_dev);
-    HIPCHK(hipEventRecord(h->ev_explore, h->stream));  // the shared flood-fill buffers are free again
+    if (own_tail < 0)
+      HIPCHK(hipEventRecord(h->ev_explore, h->stream));  // the shared flood-fill buffers are free again
     tail_stream_used = h->stream;
   }
   else if (ws.lite)

@@ -226,7 +226,7 @@ class VoFOD:
         return out, per
 
     def batch_submit(self, scans: Sequence[ScanData], tfs: np.ndarray) -> int:
-        """Enqueue a batch (read-only map); returns the ticket for `batch_collect`.  At most four in flight."""
+        """Enqueue a batch (read-only map); returns the ticket for `batch_collect`.  At most eight in flight."""
         n = len(scans)
         key = id(scans)
         cached = self._scan_arrays.get(key)
