@@ -26,10 +26,6 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# The library keeps up to a dozen HIP streams busy (key / frame / tail stages, one chain per small batch in flight); the
-# runtime deals streams onto FOUR hardware queues by default, and streams that share a queue take turns.  Read by the runtime
-# when it initialises, i.e. before the first HIP call of the process; spawned ranks inherit it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
@@ -47,7 +43,7 @@ def parse():
     ap.add_argument("--cpu-baseline-scans", type=int, default=512, help="scans timed through the CPU oracle (0 disables); ~10 s of single-thread CPU work")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--host-input-steps", type=int, default=12, help="steps of the host-resident input leg (pinned host columns, VOFOD_MEM_HOST: the nodelet's operating point); 0 disables")
-    ap.add_argument("--inflight", type=int, default=4, help="batches in flight (1..8; four keep the submission of batch k+1 off the wait for the tail of batch k-2: +3 %% over three; more gain nothing at 256 frames); their kernel chains run on streams of their own and overlap on the device")
+    ap.add_argument("--inflight", type=int, default=0, help="batches in flight (1..8; 0 = four for batches of 128 frames and more - the submission of batch k+1 then never waits for the tail of batch k-2, more gain nothing - and eight for smaller batches, whose whole chains run side by side); their kernel chains run on streams of their own and overlap on the device")
     ap.add_argument("--collective", choices=("torch", "cabi"), default="torch", help="N > 1: all-gather through torch.distributed (RCCL / gloo) or through the product's C-ABI (vofod_allgather_detections: RCCL from libvofod_hip.so)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo (CPU tensors) is for rehearsing the N>1 path on a 1-GPU box")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="every rank uses cuda:0 (only with --backend gloo)")
@@ -123,6 +119,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        # The library keeps up to a dozen HIP streams busy (key / frame / tail stages, one chain per small batch in flight); the
+        # runtime deals a process's streams onto FOUR hardware queues by default, and streams that share a queue take turns (32-frame
+        # batches: 131 k -> 227 k frames/s from this variable alone; 256-frame batches: no difference).  Read by the runtime when it
+        # initialises, i.e. before the first HIP call of the process.  Only where ONE process owns the GPU: two
+        # processes with sixteen queues each on one card (the gloo rehearsal of the N > 1 path) take turns on the hardware's
+        # queue slots - 54 k instead of 382 k frames/s - and the multi-GPU runs keep the runtime's default until measured.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
 
@@ -145,6 +149,8 @@ def main():
 
     lib = vofod_amd.library()
     F = args.frames if args.scaling == "weak" else max(4, args.frames // world)
+    if args.inflight <= 0:
+        args.inflight = 4 if F >= 128 else 8
     det = build_detector(lib, args.sensor, args.voxel_size, max(F, args.max_batch), local_rank)
     scene = synth.bench_scene()
     synth.warm_map(det, scene, args.sensor, args.map_warm_scans)

@@ -16,6 +16,6 @@ for i in 1 2 3; do timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warm
 python -c "
 import json
 for l in open('gpurun_out/${TAG}_summary/${TAG}_driver_cmd_repeat.jsonl'): d=json.loads(l); print('driver cmd', round(d['value']), round(d['ms_per_step'],4))"
-timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --rehearse-one-gpu --cpu-baseline-scans 0 --no-profile-pass --host-input-steps 0 2>/dev/null > gpurun_out/${TAG}_summary/${TAG}_rehearsal_2ranks_gloo.json
+timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --rehearse-one-gpu --cpu-baseline-scans 0 --no-profile-pass --host-input-steps 0 2>/dev/null | grep '^{' > gpurun_out/${TAG}_summary/${TAG}_rehearsal_2ranks_gloo.json
 timeout -k 10 600 python tools/bench_configs.py > gpurun_out/${TAG}_summary/${TAG}_configs_2_3_5.jsonl 2> gpurun_out/${TAG}_configs.err
 tail -c 600 gpurun_out/${TAG}_summary/${TAG}_configs_2_3_5.jsonl

@@ -751,7 +751,9 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
     CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frame2, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
   }
   h->chain_stream[0] = h->stream;
-  for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
+  // (tickets 1-3 have their streams from the start; tickets 4-7 - only small batches gain from more than four in flight - get
+  // theirs when they are first taken: streams that merely exist are not free)
+  for (int t = 1; t < 4; t++)
     CREATE_CHK(hipStreamCreateWithFlags(&h->chain_stream[t], hipStreamNonBlocking));
   for (int a = 0; a < 3; a++)
   {

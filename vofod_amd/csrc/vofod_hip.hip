@@ -1735,7 +1735,11 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     {
       for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
         if (&ws == h->slot(t))
+        {
+          if (!h->chain_stream[t])
+            HIPCHK(hipStreamCreateWithFlags(&h->chain_stream[t], hipStreamNonBlocking));
           my_stream = h->chain_stream[t];
+        }
     }
     else
     {
