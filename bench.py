@@ -516,13 +516,19 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
 
 
 def kernel_source_sha():
-    """hash of the kernel sources: ties a PMC traffic summary to the code it was measured on"""
+    """hash of the kernel sources: ties a PMC traffic summary to the code it was measured on.  Comments and white space do not
+    count (a corrected comment is not a new kernel): // and /* */ comments are cut and runs of white space collapsed before
+    hashing - crude on purpose (a "//" inside a string literal is cut too): the hash only has to change when the code does."""
     import hashlib
+    import re
 
     hsh = hashlib.sha1()
     for f in sorted((ROOT / "vofod_amd" / "csrc").glob("*.h")) + sorted((ROOT / "vofod_amd" / "csrc").glob("*.hip")):
-        hsh.update(f.read_bytes())
-    return hsh.hexdigest()
+        text = f.read_text(errors="replace")
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        hsh.update(f.name.encode() + b"\0" + " ".join(text.split()).encode())
+    return "c1:" + hsh.hexdigest()
 
 
 def cpu_baseline(args, gpu_det, host_scans):

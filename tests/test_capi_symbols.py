@@ -73,3 +73,25 @@ def test_bench_byte_model_names_the_kernels_of_the_batched_path():
     prefixes = prefixes[: prefixes.index(")")]
     for k in streaming:
         assert any(k.startswith(p) for p in re.findall(r'"(k_[a-z0-9_]+)"', prefixes)), k
+
+
+def test_kernel_source_hash_ignores_comments_and_layout(tmp_path, monkeypatch):
+    """bench.py reports PMC `traffic` only for the kernel sources it was measured on; a corrected comment or a re-wrapped line is
+    not a new kernel, a changed token is.  And the committed traffic summary belongs to the sources in the tree."""
+    import importlib
+    import json
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    assert json.loads((ROOT / "profiles" / "r03_traffic.json").read_text())["kernel_source_sha"] == bench.kernel_source_sha()
+    src = tmp_path / "vofod_amd" / "csrc"
+    src.mkdir(parents=True)
+    (src / "a.h").write_text("// a comment\nint f(int x) { return x + 1; }  /* another */\n")
+    (src / "b.hip").write_text("__global__ void k() {}\n")
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    h0 = bench.kernel_source_sha()
+    (src / "a.h").write_text("// a corrected comment\nint f(int x)\n{\n  return x + 1;\n}\n")
+    assert bench.kernel_source_sha() == h0
+    (src / "a.h").write_text("int f(int x) { return x + 2; }\n")
+    assert bench.kernel_source_sha() != h0

@@ -493,8 +493,9 @@ struct vofod_handle
   hipStream_t stream_frame = nullptr; // staged pipeline: frame kernels of all submitted batches
   hipStream_t stream_frame2 = nullptr; // frame kernels alternate between the two frame streams
   int frame_toggle = 0;
-  // Batches in flight (more than the four hardware queues the runtime maps streams onto gain nothing: eight 32-frame batches
-  // in flight measured 121 k frames/s against 132 k with three).  Slots are allocated on first use.
+  // Batches in flight.  Slots are allocated on first use.  Large batches gain nothing beyond four; small ones (whole chains side
+  // by side, tails included) gain up to eight PROVIDED their streams do not share hardware queues - the runtime deals a process's
+  // streams onto four by default (GPU_MAX_HW_QUEUES): 142 k frames/s at 32 frames with four queues, 204-289 k with 16.
   static constexpr int MAX_INFLIGHT = 8;
   hipStream_t chain_stream[MAX_INFLIGHT] = {};  // [0] == stream; in-flight batches run their chains on separate streams and overlap on the device
   Workspace wsx[MAX_INFLIGHT - 1];              // workspaces of tickets 1..7 (ticket 0 uses ws)
