@@ -188,7 +188,13 @@ typedef struct vofod_scan_debug {
   /* host wall-clock per stage, ms, reference ScopeTimer names (:924-964):
    * [0] filtering [1] clusterization [2] close X far [3] vmap update [4] classification */
   double stage_ms[8];
+  /* INPUT, batches only (read from dbg[0]): non-zero asks for the view of the production path of a read-only batch, which
+   * clusters close first - only far clusters are ever used (:727-748, :946-963): `clusters` lists the far clusters only
+   * (is_close = 0, canonical order) and `labels` is VOFOD_LABEL_NONE for every voxel outside them. */
+  int32_t far_only;
+  int32_t reserved_;
 } vofod_scan_debug;
+#define VOFOD_LABEL_NONE 0xffffffffu
 
 typedef struct vofod_status_info {
   int32_t detection_its;               /* m_detection_its */

@@ -889,6 +889,29 @@ int ORACLE_API(process_batch)(vofod_handle* h, const vofod_scan* scans, const fl
                                       dbg ? &dbg[f] : nullptr);
     if (r != VOFOD_OK)
       ret = r;
+    if (dbg && dbg[0].far_only && r == VOFOD_OK)
+    {
+      // the far-only view of include/vofod.h: the oracle clusters everything as the reference does (clusterCloud :932, then
+      // findCloseFarClusters :727-748) and shows the far part - far clusters in their order, VOFOD_LABEL_NONE elsewhere
+      vofod_scan_debug& d = dbg[f];
+      std::vector<uint32_t> far_roots;
+      size_t n_far = 0;
+      if (d.clusters && d.clusters_cap >= d.n_clusters)
+      {
+        for (size_t c = 0; c < d.n_clusters; c++)
+          if (!d.clusters[c].is_close)
+          {
+            far_roots.push_back(d.clusters[c].first_member);
+            d.clusters[n_far++] = d.clusters[c];
+          }
+        d.n_clusters = n_far;
+        std::sort(far_roots.begin(), far_roots.end());
+        if (d.labels && d.weighted_cap >= d.n_weighted)
+          for (size_t v = 0; v < d.n_weighted; v++)
+            if (!std::binary_search(far_roots.begin(), far_roots.end(), d.labels[v]))
+              d.labels[v] = VOFOD_LABEL_NONE;
+      }
+    }
     if (n_out_per_frame)
       n_out_per_frame[f] = static_cast<uint32_t>(nf);
     total += nf;

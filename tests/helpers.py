@@ -57,3 +57,17 @@ def assert_detections_equal(a, b):
     np.testing.assert_allclose(a["confidence"], b["confidence"], rtol=1e-5, atol=1e-300)
     np.testing.assert_allclose(a["detection_probability"], b["detection_probability"], rtol=1e-5)
     np.testing.assert_allclose(a["covariance"], b["covariance"], rtol=1e-5)
+
+
+def far_view(d):
+    """The far-only view of a full debug dict: what the production path of a read-only batch computes (include/vofod.h,
+    vofod_scan_debug::far_only) - only the far clusters are ever used (vofod_nodelet.cpp:727-748, :946-963).  The cluster
+    table keeps its (canonical) order, labels outside the far clusters become LABEL_NONE."""
+    cl = d["clusters"]
+    far = cl[cl["is_close"] == 0]
+    lab = d["labels"].copy()
+    lab[~np.isin(lab, far["first_member"])] = capi.LABEL_NONE
+    out = dict(d)
+    out["clusters"] = far
+    out["labels"] = lab
+    return out

@@ -1,0 +1,136 @@
+"""Close-first clustering (round 4): read-only batches cluster the FAR voxels only - the reference never uses anything else
+of a scan's clusters (findCloseFarClusters, vofod_nodelet.cpp:727-748: a cluster is close as soon as one member has a
+background voxel within hasCloseTo's stencil; :946-963: only far_clusters_indices reach classifyClusters / extractDetections).
+The HIP path's far-only debug view (cluster table of the far clusters, labels of their voxels) must equal the far part of the
+oracle's FULL clustering bit for bit, and the detections must be the oracle's."""
+import numpy as np
+import pytest
+
+from vofod_amd import capi, synth
+from vofod_amd.detector import ScanData
+
+from helpers import assert_detections_equal, assert_scan_debug_equal, far_view, make_pair, sync_maps
+
+pytestmark = pytest.mark.gpu
+
+
+def _rebase(got, want):
+    got = got.copy()
+    if len(got) and len(want):
+        got["id"] += want["id"][0] - got["id"][0]
+    return got
+
+
+def _check_far_view(ref, dev, scans, tfs, expect_close_first=None):
+    """oracle: full clustering, cut down to its far part; HIP: the far-only view (close-first kernel, or the full clustering
+    cut down by the library when a frame does not take it); then the production call without debug output"""
+    da, pa, ga = ref.process_batch(scans, tfs, debug=True)
+    db, pb, gb = dev.process_batch(scans, tfs, debug=True, far_only=True)
+    np.testing.assert_array_equal(pb, pa)
+    assert_detections_equal(da, _rebase(db, da))
+    for f, (x, y) in enumerate(zip(ga, gb)):
+        try:
+            assert_scan_debug_equal(far_view(x), y)
+        except AssertionError as e:
+            raise AssertionError(f"frame {f}: {e}") from e
+    dc, pc = dev.process_batch(scans, tfs)  # no debug output: close first + device tail
+    np.testing.assert_array_equal(pc, pa)
+    assert_detections_equal(da, _rebase(dc, da))
+    t = [dev.batch_submit(scans, tfs) for _ in range(2)]
+    for tk in t:
+        dd, pd = dev.batch_collect(tk)
+        np.testing.assert_array_equal(pd, pa)
+        assert_detections_equal(da, _rebase(dd, da))
+    return ga, gb, da
+
+
+@pytest.mark.parametrize("sensor,vs,n_frames,warm", [("os1-128", 0.25, 12, 12), ("os1-16", 0.25, 6, 8), ("os1-128", 0.25, 5, 0)])
+def test_far_view_on_warmed_maps(oracle, hip, sensor, vs, n_frames, warm):
+    """scenes with floating targets that appear after the map was warmed (warm = 0: only the seeded ground patch is known)"""
+    ref, dev = make_pair(oracle, hip, sensor, vs, max_batch=n_frames)
+    warm_scene = synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=0)
+    scene = synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=8)
+    if warm:
+        synth.warm_map(dev, warm_scene, sensor, warm)
+    else:
+        synth.seed_ground(dev)
+    if dev.status().background_pts_sufficient and dev.status().sure_background_sufficient:
+        ref.load_apriori(np.zeros((0, 3), dtype=np.float32))
+    sync_maps(dev, ref)
+    frames = synth.bench_frames(scene, sensor, n_frames)
+    ga, gb, da = _check_far_view(ref, dev, [s.scan for s in frames], np.stack([s.tf for s in frames]))
+    n_far = [int((g["clusters"]["is_close"] == 0).sum()) for g in ga]
+    assert max(n_far) >= 2, n_far
+    assert all(int(g["clusters"]["is_close"].sum()) >= 1 for g in ga)
+
+
+@pytest.mark.parametrize("sensor", ["os1-16", "os1-128"])
+def test_cold_map_everything_is_far(oracle, hip, sensor):
+    """a map without any background voxel: every voxel is far, every cluster a far cluster.  OS1-16 frames keep within the
+    close-first path's capacity (hundreds of pure-far bricks, tens of components); OS1-128 frames exceed it (thousands of
+    bricks) and take the full clustering inside the same launch.  Both latches set: the flood fills run on every candidate."""
+    n = 6
+    ref, dev = make_pair(oracle, hip, sensor, 0.25, max_batch=n)
+    for d in (ref, dev):
+        d.load_apriori(np.zeros((0, 3), dtype=np.float32))  # latches only
+    scene = synth.make_scene(5, n_targets=6)
+    frames = synth.bench_frames(scene, sensor, n)
+    ga, gb, da = _check_far_view(ref, dev, [s.scan for s in frames], np.stack([s.tf for s in frames]))
+    for g in ga:
+        assert int(g["clusters"]["is_close"].sum()) == 0
+        assert len(g["clusters"]) >= 2
+
+
+def _cells_scan(pts_world, t, w=1024, h=16):
+    """a scan whose returns are the given world points, seen from a sensor at `t` (pose = pure translation)"""
+    n = w * h
+    p = np.asarray(pts_world, dtype=np.float64) - np.asarray(t, dtype=np.float64)
+    assert len(p) <= n
+    cols = [np.zeros(n, dtype=np.float32) for _ in range(3)]  # (0,0,0) = no return: dropped by the exclude box
+    for a in range(3):
+        cols[a][: len(p)] = p[:, a]
+    return ScanData(x=cols[0], y=cols[1], z=cols[2], width=w, height=h, stride_bytes=4)
+
+
+def test_far_blobs_at_exactly_the_tolerance_from_close_voxels(oracle, hip):
+    """Lattice pairs (close voxel c, far voxel f = c + D) with |D|^2 = 35, 36, 37 cells at tolerance 1.5 m / 0.25 m voxels =
+    6 cells: 35 joins (f's cluster is close), 36 is exactly the tolerance and must NOT join (strict d^2 < tol^2, FLANN's
+    float expression decides on the boundary), 37 does not.  c is a scan voxel 6 cells above a background sheet (hasCloseTo's
+    truncated norm: 6 <= 6.0, close), f lies 7..12 cells above the sheet (outside the half-open cube: far by itself), the
+    pairs are 40 cells apart.  Four frames, the pairs shifted from frame to frame."""
+    vs = 0.25
+    ref, dev = make_pair(oracle, hip, "os1-16", vs, max_batch=4)
+    ox, oy, oz = dev.map_offset
+    ix, iy = np.meshgrid(np.arange(20, 220), np.arange(20, 200), indexing="ij")
+    sheet = np.stack([ox + (ix.ravel() + 0.5) * vs, oy + (iy.ravel() + 0.5) * vs, np.full(ix.size, oz + 8.5 * vs)], axis=1).astype(np.float32)
+    for d in (ref, dev):
+        d.load_apriori(sheet)  # background sheet in map layer 8 (+inf voxels), both latches
+    offsets = {35: [(5, 3, 1), (3, 1, 5), (1, 5, 3), (-5, 1, 3), (3, -5, 1)], 36: [(0, 0, 6), (4, 4, 2), (-4, 2, 4), (2, -4, 4), (4, -2, 4)],
+               37: [(6, 0, 1), (1, 0, 6), (0, 6, 1), (-6, 0, 1), (0, 1, 6)]}
+    t = (50.0, 40.0, 10.0)
+    frames, truth = [], []
+    for fidx in range(4):
+        cells, want, k = [], [], 0
+        for d2, offs in offsets.items():
+            for (dx, dy, dz) in offs:
+                assert dx * dx + dy * dy + dz * dz == d2 and dz >= 1
+                c = (40 + 40 * (k % 4) + fidx, 40 + 40 * (k // 4) + 2 * fidx, 8 + 6)
+                f = (c[0] + dx, c[1] + dy, c[2] + dz)
+                k += 1
+                cells += [c, f]
+                want.append((d2, f))
+        pts = [(ox + (a + 0.5) * vs, oy + (b + 0.5) * vs, oz + (c_ + 0.5) * vs) for (a, b, c_) in cells]
+        frames.append(_cells_scan(pts, t))
+        truth.append(want)
+    tf = np.float32([[1, 0, 0, t[0]], [0, 1, 0, t[1]], [0, 0, 1, t[2]]])
+    ga, gb, da = _check_far_view(ref, dev, frames, np.stack([tf] * 4))
+    # what the oracle decided, spelled out: a far voxel 35 from a close one is in no far cluster, at 36 and 37 it is
+    for g, want in zip(ga, truth):
+        w = g["weighted"]
+        assert len(w) == 2 * len(want)
+        lab = far_view(g)["labels"]
+        for d2, f in want:
+            fx, fy, fz = ox + (f[0] + 0.5) * vs, oy + (f[1] + 0.5) * vs, oz + (f[2] + 0.5) * vs
+            hit = np.flatnonzero((np.abs(w["x"] - fx) < 0.01) & (np.abs(w["y"] - fy) < 0.01) & (np.abs(w["z"] - fz) < 0.01))
+            assert len(hit) == 1, (d2, f)
+            assert (lab[hit[0]] != capi.LABEL_NONE) == (d2 >= 36), (d2, f)

@@ -137,7 +137,12 @@ class ScanDebug(C.Structure):
         ("background_pts_sufficient", C.c_int32),
         ("sure_background_sufficient", C.c_int32),
         ("stage_ms", C.c_double * 8),
+        ("far_only", C.c_int32),  # input (batches): the close-first view - far clusters only, LABEL_NONE elsewhere
+        ("reserved_", C.c_int32),
     ]
+
+
+LABEL_NONE = 0xFFFFFFFF
 
 
 class StatusInfo(C.Structure):

@@ -46,6 +46,7 @@ struct FrameHdr
   uint32_t n_bricks;    // occupied 4x4x4 bricks (brick-level clustering)
   uint32_t n_undecided; // voxels whose own map row is empty: k_closefar_sweep tests their whole stencil
   int32_t slab_y0, slab_y1;  // frames split into y-slabs (k_frame_lds<true>): the lattice rows [y0, y1) this slab owns
+  uint32_t far_only;         // k_frame_lds clustered close first: the cluster table holds the far clusters only, no labels were written
 };
 
 // Parameters constant over a call (passed by value).

@@ -33,6 +33,9 @@ namespace vk
 {
 
 constexpr int FR_THREADS = 1024;
+#ifndef FR_VGPRS
+#define FR_VGPRS 112  /* 4 waves per SIMD x 112 leave 64 registers per lane and SIMD: one guest wave of k_key1 / k_explore beside a frame workgroup */
+#endif
 #ifndef FR_WRITE_BACK_DEF
 #define FR_WRITE_BACK_DEF 1
 #endif
@@ -48,6 +51,12 @@ constexpr uint32_t FR_ROWS_MAX = 8192;    // brick rows (nby * nbz) the per-fram
 constexpr uint32_t FR_CODE_NONE = 0xffffffffu;
 constexpr int FR_BB64 = FR_BW64 + 2 + FR_BW64 / 4;  // 64-bit words of the bitmap (+ 2 guard words) followed by its 16-bit prefix array
 constexpr uint32_t FR_CNT_CAP = FR_BB64 * 8;       // per-voxel byte counters that fit the same storage
+constexpr int CF_MAX = FR_THREADS;                 // close-first clustering: pure-far bricks per frame (one per thread); a frame with more takes the full clustering
+#ifndef CF_G_DEF
+#define CF_G_DEF 4
+#endif
+constexpr int CF_G = CF_G_DEF;                     // bricks per thread whose map lookups are in flight together (close-first, first part)
+constexpr uint32_t CF_LABEL_NONE = 0xffffffffu;    // label of a voxel outside the far clusters in the far-only debug view
 
 // per-frame scratch in global memory (L2-resident: touched sparsely)
 struct FrameScratch
@@ -620,12 +629,12 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
 // halo voxel is the same voxel as an own voxel of the next slab: k_slab_merge joins the slabs' components through those twins,
 // interleaves the slabs' voxel lists plane by plane into the frame's key order and writes the frame's records to slot f.
 template <bool SLABS>
-__global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
+__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS))) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
                                                          VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
                                                          const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
                                                          const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,
                                                          CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof, const RefLattice rl, const FrameArgs* __restrict__ args,
-                                                         uint32_t n_src, uint32_t n_slabs)
+                                                         uint32_t n_src, uint32_t n_slabs, int close_first)
 {
   __shared__ __attribute__((aligned(16))) unsigned long long s_bb[FR_BB64];  // brick-lattice bitmap (bit = linear brick id) + exclusive popcount prefix per
                                                                             // 64-bit word; during the counting / rank phases: one byte counter per voxel
@@ -638,6 +647,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint32_t s_wsum[FR_THREADS / 64];
   __shared__ uint32_t s_n, s_nh, s_nn, s_nf, s_no, s_ne;
   __shared__ uint32_t s_nhn;  // both adjacent-hit counters of the probe: face neighbours << 17 | others (<= 3 and 10 per brick)
+  // close-first clustering (round 4, see the block behind phase 3a): the frame's pure-far bricks
+  __shared__ uint16_t s_pf[CF_MAX];     // their nodes
+  __shared__ uint16_t s_pfpar[CF_MAX];  // union-find over the list's indices
+  __shared__ uint32_t s_taint[CF_MAX / 32], s_troot[CF_MAX / 32];  // bit k: list entry k has an edge to a brick with a close voxel / the component rooted at k holds such an entry
+  __shared__ uint32_t s_npf, s_nc, s_ncand;
   unsigned long long* s_bits64 = s_bb;
   uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
   uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
@@ -709,7 +723,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     s_nn = 0;
     s_nf = 0;
     s_no = 0;
+    s_npf = 0;
+    s_nc = 0;
+    s_ncand = 0;
   }
+  if (tid < CF_MAX / 32)
+    s_taint[tid] = s_troot[tid] = 0u;
   __syncthreads();
   const uint32_t* codes = sa.keys + static_cast<size_t>(FRAME) * pt_cap;      // the list the passes 3a / 3b read (slab mode: this slab's codes)
   const uint32_t* codes_src = sa.keys + static_cast<size_t>(SRC) * pt_cap;    // k_key1's list of the whole frame
@@ -1135,6 +1154,155 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   }
   __syncthreads();
   FR_STAMP(3);
+  // ---- close first (round 4).  The reference only ever uses the FAR clusters (findCloseFarClusters, vofod_nodelet.cpp:727-748:
+  // a cluster is close as soon as ONE member has a background voxel within hasCloseTo's stencil; close clusters feed nothing
+  // but a per-voxel map update, :946) - and on a warmed map the ground sheet and the buildings, one giant close component, are
+  // > 95 % of a frame.  The dilated map image answers hasCloseTo for a voxel with one bit, and a 4x4x4 brick is a clique under
+  // the tolerance (brick-level clustering is only planned then), so:
+  //   * a brick that holds a close voxel belongs to a close cluster as a whole;
+  //   * a far cluster is a connected component of bricks WITHOUT any close voxel ("pure-far" bricks) that has no edge to a
+  //     brick with one: walk from any of its voxels towards a close voxel - the last far voxel on the way has that edge.
+  // Here: which bricks are pure far (one lookup of the dilated image per occupied lattice row of a brick, until the first hit).
+  // Behind the emission: edges and unions around those few bricks only (tens to hundreds per frame instead of ~5 000).
+  // Same member lists, sizes, smallest members, hence the same candidates and detections as the full clustering; that one
+  // stays for the debug view of ALL clusters, for slabs, and for a frame with more than CF_MAX pure-far bricks (a cold map).
+  bool cf = false;
+  if constexpr (!SLABS)
+  {
+#ifdef CF_BISECT3
+    if (false)
+#else
+    if (close_first && mapclose)
+#endif
+    {
+      constexpr int NPT = LB_MAX / FR_THREADS;
+      const bool mapk_ok = s_mapk[3] != 0;
+      const int K0 = s_mapk[0], K1 = s_mapk[1], K2 = s_mapk[2];
+      // one voxel by itself (a brick that leaves the map, or a lattice that is no translate of the map's): as phase E
+      auto voxel_close = [&](int k0, int k1, int k2) -> bool {
+        int mx_, my_, mz_;
+        if (mapk_ok)
+        {
+          mx_ = k0 + K0;
+          my_ = k1 + K1;
+          mz_ = k2 + K2;
+        }
+        else
+        {
+          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), hoff0);
+          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), hoff1);
+          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), hoff2);
+          mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
+          my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
+          mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
+        }
+        if (mx_ >= 0 && mx_ < mg.sx && my_ >= 0 && my_ < mg.sy && mz_ >= 0 && mz_ < mg.sz)
+        {
+          const uint64_t L = (static_cast<uint64_t>(mz_) * mg.sy + my_) * mg.sx + mx_;
+          return ((mapclose[L >> 6] >> (L & 63)) & 1ull) != 0ull;
+        }
+        bool hit = false;  // a centre outside the map (a point on the far face of the operation area): the clipped stencil sweep
+        for (int rr = 0; rr < n_crows && !hit; rr++)
+          hit = close_row_hit(mg, mapbits, crows[rr], mx_, my_, mz_);
+        return hit;
+      };
+      // Rounds: every round looks up ONE occupied lattice row (4 cells along x: 4 bits of the image, fetched as the two bytes
+      // that hold them) of each of the thread's bricks that is still undecided - the lookups of a round are in flight
+      // together, CF_G bricks per thread at a time.  Consecutive lanes hold consecutive nodes, i.e. neighbouring bricks of a
+      // brick row: their lookups fall into the same lines of the image.
+      const unsigned char* mc8 = reinterpret_cast<const unsigned char*>(mapclose);
+#pragma unroll
+      for (int g0 = 0; g0 < NPT; g0 += CF_G)
+      {
+        uint32_t rem[CF_G];  // bit r: lattice row r = yy + 4 zz of the brick is occupied and not looked up yet
+        uint32_t far_m = 0;  // bit j: the group's j-th brick has shown no close voxel so far
+#pragma unroll
+        for (int j = 0; j < CF_G; j++)
+        {
+          const uint32_t i = (g0 + j) * FR_THREADS + tid;
+          rem[j] = 0u;
+          if (g0 + j < NPT && i < n)
+          {
+            unsigned long long t = s_word[i];
+            t |= t >> 1;
+            t |= t >> 2;
+            uint32_t lo = static_cast<uint32_t>(t) & 0x11111111u, hi = static_cast<uint32_t>(t >> 32) & 0x11111111u;
+            lo = (lo | (lo >> 3) | (lo >> 6) | (lo >> 9)) & 0x000f000fu;
+            hi = (hi | (hi >> 3) | (hi >> 6) | (hi >> 9)) & 0x000f000fu;
+            rem[j] = (lo & 0xfu) | (lo >> 12) | ((hi & 0xfu) << 8) | ((hi >> 4) & 0xf000u);
+            far_m |= 1u << j;
+          }
+        }
+        for (;;)
+        {
+          uint32_t val[CF_G], meta[CF_G];  // meta: nibble | shift << 4 | looked up << 8
+          bool any = false;
+#pragma unroll
+          for (int j = 0; j < CF_G; j++)
+          {
+            val[j] = meta[j] = 0u;
+            if (!rem[j])
+              continue;
+            any = true;
+            const uint32_t i = (g0 + j) * FR_THREADS + tid;
+            const int row = __ffs(static_cast<int>(rem[j])) - 1;
+            rem[j] &= rem[j] - 1u;
+            const uint32_t xyz = s_xyz[i];
+            const uint32_t nib = static_cast<uint32_t>(s_word[i] >> (4 * row)) & 0xfu;
+            const int k0 = 4 * fr_bx(xyz), k1 = 4 * fr_by(xyz) + (row & 3), k2 = 4 * fr_bz(xyz) + (row >> 2);
+            const int mx0 = k0 + K0, my_ = k1 + K1, mz_ = k2 + K2;
+            if (mapk_ok && mx0 >= 0 && mx0 + 3 < mg.sx && my_ >= 0 && my_ < mg.sy && mz_ >= 0 && mz_ < mg.sz)
+            {
+              const uint64_t L = (static_cast<uint64_t>(mz_) * mg.sy + my_) * mg.sx + mx0;
+              meta[j] = nib | (static_cast<uint32_t>(L & 7u) << 4) | 0x100u;
+              const unsigned char* q = mc8 + (L >> 3);  // (the image ends with two guard words)
+              val[j] = static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8);
+            }
+            else
+            {
+              bool hit = false;
+              for (int xx = 0; xx < 4 && !hit; xx++)
+                if ((nib >> xx) & 1u)
+                  hit = voxel_close(k0 + xx, k1, k2);
+              if (hit)
+              {
+                rem[j] = 0u;
+                far_m &= ~(1u << j);
+              }
+            }
+          }
+          if (!any)
+            break;
+#pragma unroll
+          for (int j = 0; j < CF_G; j++)
+            if ((meta[j] & 0x100u) && ((val[j] >> ((meta[j] >> 4) & 7u)) & meta[j] & 0xfu))
+            {
+              rem[j] = 0u;
+              far_m &= ~(1u << j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CF_G; j++)
+        {
+          const bool pf = (far_m >> j) & 1u;
+          const unsigned long long m = __ballot(pf);
+          if (!m)
+            continue;
+          const int leader = __ffsll(static_cast<long long>(m)) - 1;
+          uint32_t base = 0;
+          if (lane == leader)
+            base = atomicAdd(&s_npf, static_cast<uint32_t>(__popcll(m)));
+          base = __builtin_amdgcn_readlane(base, leader);
+          const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (pf && pos < static_cast<uint32_t>(CF_MAX))
+            s_pf[pos] = static_cast<uint16_t>((g0 + j) * FR_THREADS + tid);
+        }
+      }
+      __syncthreads();
+      cf = s_npf <= static_cast<uint32_t>(CF_MAX);
+    }
+  }
+  FR_STAMP(15);
   // ---- 3b: weights (voxel_grid_weighted.cpp:181).  The bitmap is parked in global memory; its LDS becomes one byte
   // counter per voxel, indexed in brick order: first voxel of the node + set bits below.  Consecutive equal codes of a
   // thread add once.  A counter that would pass 255 is undone and the points go to the frame's record list
@@ -1441,6 +1609,32 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   }
   __syncthreads();
   FR_STAMP(5);
+  // (the rank of a voxel, as pass d below computes it - for the close-first path, which comes back to its few far bricks later)
+  auto rank_ctx = [&](uint32_t i, uint32_t xyz, unsigned long long (&M)[4], uint32_t (&Q)[4]) {
+    const uint32_t row = fr_row(xyz, nby);
+    const ulonglong2 a0 = nodeA[2 * i], a1 = nodeA[2 * i + 1];
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(rowT + static_cast<size_t>(row) * 4);
+    const ulonglong2 t0 = src[0], t1 = src[1];
+    const uint4 qq = *reinterpret_cast<const uint4*>(rowQ + static_cast<size_t>(row) * 4);
+    M[0] = fr_excl16(t0.x) + a0.x;
+    M[1] = fr_excl16(t0.y) + a0.y;
+    M[2] = fr_excl16(t1.x) + a1.x;
+    M[3] = fr_excl16(t1.y) + (a1.y & ~FR_BEGAN);
+    if (!(a1.y & FR_BEGAN))
+    {
+#pragma unroll
+      for (int zz = 0; zz < 4; zz++)
+        M[zz] += s_cin[i >> 6][zz];
+    }
+    Q[0] = qq.x, Q[1] = qq.y, Q[2] = qq.z, Q[3] = qq.w;
+  };
+  auto rank_of = [&](unsigned long long W, int p, const unsigned long long (&M)[4], const uint32_t (&Q)[4]) -> uint32_t {
+    const int zz = p >> 4, yy = (p >> 2) & 3, xx = p & 3;
+    const unsigned long long Mz = zz == 0 ? M[0] : zz == 1 ? M[1] : zz == 2 ? M[2] : M[3];
+    const uint32_t Qz = zz == 0 ? Q[0] : zz == 1 ? Q[1] : zz == 2 ? Q[2] : Q[3];
+    const uint32_t nib = static_cast<uint32_t>(W >> (p & ~3)) & 0xfu;
+    return Qz + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
+  };
   // Pass d: the voxel records leave at their ranks (voxel_grid_weighted.cpp:171-188): centre, weight 1 (+ extras below),
   // node of the brick (for the label pass); the lattice key only for the general kernels that may follow (!write_tables).
   for (uint32_t i = tid; i < n; i += FR_THREADS)
@@ -1488,10 +1682,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       pt.z = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), hoff2);
       pt.w = __uint_as_float(static_cast<uint32_t>(*cntp++));  // points in the voxel (the record list below adds what a byte cannot hold)
       va.pts[rank] = pt;  // (through L2 on purpose: it merges the scattered 16-byte records into lines; non-temporal stores cost 21 % of the throughput)
-      reinterpret_cast<uint16_t*>(va.bb)[rank] = static_cast<uint16_t>(i);  // (node < LB_MAX: 16 bits; the general kernels keep 32-bit brick codes here)
+      if (!cf)  // (the label pass of the full clustering finds a voxel's brick here; the close-first path has no such pass)
+        reinterpret_cast<uint16_t*>(va.bb)[rank] = static_cast<uint16_t>(i);  // (node < LB_MAX: 16 bits; the general kernels keep 32-bit brick codes here)
       if (!write_tables || SLABS)
         va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
-      if (first)
+      if (first && !cf)
         bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
       first = false;
     }
@@ -1550,11 +1745,21 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     for (int i = tid; i < FR_BB64 / 2; i += FR_THREADS)
       reinterpret_cast<ulonglong2*>(s_bb)[i] = bsave[i];
   }
+  uint16_t* s_pfidx = reinterpret_cast<uint16_t*>(s_x2);  // close-first: node -> index in the pure-far list, 0xffff: the brick holds a close voxel
   for (uint32_t i = tid; i < n; i += FR_THREADS)
-    s_par[i] = static_cast<uint16_t>(i);
+    s_par[i] = cf ? static_cast<uint16_t>(0xffffu) : static_cast<uint16_t>(i);  // (s_pfidx and s_par are the same storage)
   if (tid == 0)
     h.V = V;
   __syncthreads();
+  if (cf)
+  {
+    for (uint32_t k = tid; k < s_npf; k += FR_THREADS)
+    {
+      s_pfidx[s_pf[k]] = static_cast<uint16_t>(k);
+      s_pfpar[k] = static_cast<uint16_t>(k);
+    }
+    __syncthreads();
+  }
   FR_STAMP(7);
   constexpr int VU = 8;  // voxel records fetched per lane and round in the label pass
   const uint32_t Vround = (V + 63u) & ~63u;
@@ -1570,7 +1775,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   // two hit lists.  Bricks two apart are looked at after these have been merged - and then only around the bricks outside
   // the largest component (D-a2 below): a pair inside one component has nothing left to decide.
   const uint32_t cap_axis = 3u * n, cap_near = 10u * n;
-  if (hcap < 14u * n)
+  if (!cf && hcap < 14u * n)
   {
     if (tid == 0)
     {
@@ -1621,6 +1826,236 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     nb0 = pre + __popcll(w0 & ((1ull << sh) - 1ull));  // node of the first occupied brick at or after `firstb`
     return raw << shw;
   };
+  auto is_cand = [&](uint32_t close, uint32_t size, const int* box) {
+    int ext_ok = 1;
+    for (int a = 0; a < 3; a++)
+      ext_ok &= (static_cast<float>(box[3 + a] - box[a]) * g.leaf[a] <= up.cand_max_extent);
+    return !close && static_cast<int>(size) >= up.min_points && ext_ok;
+  };
+#ifdef CF_BISECT4
+  if (false)
+#else
+  if (cf)
+#endif
+  {
+    // ---- close first, continued: edges and unions around the pure-far bricks (list entry k <-> thread k from F-b on).
+    // F-a: work item = (pure-far brick, row of the half stencil, direction), as phase D-a2 of the full clustering.  A neighbour
+    // brick with a close voxel taints the entry (both directions: the neighbour is in nobody's list); a pure-far neighbour
+    // is joined (forward direction only: the pair is seen from its base brick).  Octant matrices first, the exact ball test
+    // (FLANN's float expression on the tolerance's boundary) for what they leave open.
+    const uint32_t n_pf = s_npf;
+    auto tainted = [&](uint32_t k) -> bool { return ((*reinterpret_cast<volatile uint32_t*>(&s_taint[k >> 5]) >> (k & 31u)) & 1u) != 0u; };
+    {
+      const uint32_t items = n_pf * 32u;
+      const int row = (tid >> 1) & 15, back = tid & 1;
+      int ddy, ddz;
+      uint32_t valid, axis, near;
+      unsigned long long ov;
+      load_row(row, ddy, ddz, valid, axis, near, ov);
+      uint32_t slots = valid;
+      if (back)
+      {
+        uint32_t rev = 0;  // the neighbour is the pair's base brick: it sees this brick at (-dx, ddy, ddz), i.e. slot 2R - s
+        for (int sl = 0; sl <= 2 * R; sl++)
+          rev |= ((valid >> (2 * R - sl)) & 1u) << sl;
+        slots = rev;
+      }
+      if (slots)
+        for (uint32_t it = tid; it < items; it += FR_THREADS)
+        {
+          const uint32_t k = it >> 5;
+          const uint32_t t = s_pf[k];
+          const uint32_t xa = s_xyz[t];
+          const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
+          const int ny = by + (back ? -ddy : ddy), nz = bz + (back ? -ddz : ddz);
+          if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
+            continue;
+          uint32_t raw, nb0;
+          int shw;
+          uint32_t win = window(bx, ny, nz, raw, nb0, shw) & slots;
+          while (win)
+          {
+            const int sl = __ffs(static_cast<int>(win)) - 1;
+            win &= win - 1;
+            const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+            const uint32_t k2 = s_pfidx[t2];
+            const bool other_close = k2 == 0xffffu;
+            if (other_close)
+            {
+              if (tainted(k))
+                continue;
+            }
+            else if (back || lb_find(s_pfpar, k) == lb_find(s_pfpar, k2))
+              continue;
+            const uint32_t xb = s_xyz[t2];
+            const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
+            const uint32_t A8 = (back ? xb : xa) >> 24, B8 = (back ? xa : xb) >> 24;  // (the matrices are indexed base brick x brick at the offset)
+            bool conn = lb_octtest(s_tab.oct[2 * o], A8, B8);
+#ifndef CF_BISECT1
+            if (!conn && lb_octtest(s_tab.oct[2 * o + 1], A8, B8))
+#else
+            if (false)
+#endif
+              conn = lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, fr_bx(xb) - bx, fr_by(xb) - by, fr_bz(xb) - bz);
+            if (!conn)
+              continue;
+            if (other_close)
+              atomicOr(&s_taint[k >> 5], 1u << (k & 31u));
+            else
+            {
+              uint32_t ra = lb_find(s_pfpar, k), rb = lb_find(s_pfpar, k2);
+              while (ra != rb)  // hook the larger root under the smaller
+              {
+                if (ra < rb)
+                {
+                  const uint32_t tmp = ra;
+                  ra = rb;
+                  rb = tmp;
+                }
+                const uint32_t old = lb_cas16(s_pfpar, ra, ra, rb);
+                if (old == ra)
+                  break;
+                ra = old;
+              }
+            }
+          }
+        }
+    }
+    __syncthreads();  // (the bitmap is dead from here on: its storage holds the components' accumulators, indexed by the root's list index)
+    FR_STAMP(8);
+    uint32_t* a_size = reinterpret_cast<uint32_t*>(s_bb);
+    uint32_t* a_min = a_size + CF_MAX;
+    int* a_box = reinterpret_cast<int*>(a_min + CF_MAX);
+    uint8_t* a_cand = reinterpret_cast<uint8_t*>(a_box + 6 * CF_MAX);
+    static_assert(static_cast<size_t>(CF_MAX) * 33u <= sizeof(unsigned long long) * FR_BB64, "the accumulators of the close-first path live in the bitmap's storage");
+    static_assert(CF_MAX == FR_THREADS, "one pure-far brick per thread");
+    const uint32_t k = tid;
+    const bool live = k < n_pf;
+    uint32_t root = k;
+    if (live)
+    {
+      uint32_t p;
+      while ((p = lb_ld16(s_pfpar, root)) != root)
+        root = p;
+      a_size[k] = 0u;
+      a_min[k] = 0xffffffffu;
+      for (int a = 0; a < 3; a++)
+      {
+        a_box[6 * k + a] = 0x7fffffff;
+        a_box[6 * k + 3 + a] = static_cast<int>(0x80000000u);
+      }
+      a_cand[k] = 0;
+    }
+    __syncthreads();
+    // F-b: sizes, lattice boxes, smallest members (= labels: rank of the first voxel of one of the component's bricks), taint
+    unsigned long long W = 0ull, M[4] = {0ull, 0ull, 0ull, 0ull};
+    uint32_t Q[4] = {0u, 0u, 0u, 0u};
+    if (live)
+    {
+      const uint32_t node = s_pf[k];
+      const uint32_t xyz = s_xyz[node];
+      W = s_word[node];
+      rank_ctx(node, xyz, M, Q);
+      const uint32_t first = rank_of(W, __ffsll(static_cast<long long>(W)) - 1, M, Q);
+      const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
+      unsigned long long t = W | (W >> 16) | (W >> 32) | (W >> 48);
+      uint32_t ox = static_cast<uint32_t>(t) & 0xffffu;
+      ox = (ox | (ox >> 4) | (ox >> 8) | (ox >> 12)) & 0xfu;
+      t = W | (W >> 1);
+      t |= t >> 2;  // bit 4y + 16z: row (y,z) is occupied
+      const unsigned long long ty = t | (t >> 16) | (t >> 32) | (t >> 48);
+      const uint32_t oy = (static_cast<uint32_t>(ty) & 1u) | ((static_cast<uint32_t>(ty) >> 3) & 2u) | ((static_cast<uint32_t>(ty) >> 6) & 4u) | ((static_cast<uint32_t>(ty) >> 9) & 8u);
+      const uint32_t oz = ((W & 0xffffull) ? 1u : 0u) | ((W & 0xffff0000ull) ? 2u : 0u) | ((W & 0xffff00000000ull) ? 4u : 0u) | ((W >> 48) ? 8u : 0u);
+      const int lo[3] = {4 * bx + __ffs(static_cast<int>(ox)) - 1, 4 * by + __ffs(static_cast<int>(oy)) - 1, 4 * bz + __ffs(static_cast<int>(oz)) - 1};
+      const int hi[3] = {4 * bx + 31 - __clz(static_cast<int>(ox)), 4 * by + 31 - __clz(static_cast<int>(oy)), 4 * bz + 31 - __clz(static_cast<int>(oz))};
+      atomicAdd(&a_size[root], static_cast<uint32_t>(__popcll(W)));
+      atomicMin(&a_min[root], first);
+      for (int a = 0; a < 3; a++)
+      {
+        atomicMin(&a_box[6 * root + a], lo[a]);
+        atomicMax(&a_box[6 * root + 3 + a], hi[a]);
+      }
+      if (tainted(k))
+        atomicOr(&s_troot[root >> 5], 1u << (root & 31u));
+    }
+    __syncthreads();
+    FR_STAMP(9);
+    // F-c: the surviving components ARE far_clusters_indices of vofod_nodelet.cpp:746: their records (close = 0) make the frame's
+    // cluster table, the voxels of the candidates among them (enough points, small enough to pass max_size) the member list
+    ClusterRec* table = table_all + static_cast<size_t>(FRAME) * g.vox_cap;
+    CandMember* cands = cand_all + static_cast<size_t>(FRAME) * g.vox_cap;
+    const bool surv = live && !((s_troot[root >> 5] >> (root & 31u)) & 1u);
+    if (surv && root == k)
+    {
+      const bool cand = is_cand(0u, a_size[k], &a_box[6 * k]);
+      a_cand[k] = cand ? 1 : 0;
+      ClusterRec rec;
+      rec.root = a_min[k];
+      rec.size = a_size[k];
+      for (int a = 0; a < 3; a++)
+      {
+        rec.imin[a] = a_box[6 * k + a];
+        rec.imax[a] = a_box[6 * k + 3 + a];
+      }
+      rec.close = 0u;
+      rec.cand = cand ? 1u : 0u;
+      table[atomicAdd(&s_nc, 1u)] = rec;
+    }
+    if (close_first == 2)  // the far-only debug view: a label for every voxel
+      for (uint32_t v = tid; v < V; v += FR_THREADS)
+        labels[v] = CF_LABEL_NONE;
+    __syncthreads();
+    FR_STAMP(10);
+#ifdef CF_BISECT2
+    if (false)
+#else
+    if (surv && (a_cand[root] || close_first == 2))
+#endif
+    {
+      const bool cand = a_cand[root] != 0;
+      const uint32_t label = a_min[root];
+      uint32_t pos = cand ? atomicAdd(&s_ncand, static_cast<uint32_t>(__popcll(W))) : 0u;
+      unsigned long long w = W;
+      while (w)
+      {
+        const int p = __ffsll(static_cast<long long>(w)) - 1;
+        w &= w - 1;
+        const uint32_t rank = rank_of(W, p, M, Q);
+        if (cand)
+        {
+          CandMember cm;
+          cm.root = label;
+          cm.v = rank;
+          cands[pos++] = cm;
+        }
+        if (close_first == 2)
+          labels[rank] = label;
+      }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      h.C = s_nc;
+      h.n_cand = s_ncand;
+      h.n_bricks = n;
+      h.far_only = 1u;
+    }
+    FR_STAMP(11);
+    FR_STAMP(12);
+    FR_STAMP(13);
+    if (prof && tid == 0)
+    {
+      prof[static_cast<size_t>(FRAME) * 32 + 24] = n_pf;
+      prof[static_cast<size_t>(FRAME) * 32 + 25] = s_nc;
+      prof[static_cast<size_t>(FRAME) * 32 + 26] = n;
+      prof[static_cast<size_t>(FRAME) * 32 + 27] = n_keys;
+      prof[static_cast<size_t>(FRAME) * 32 + 28] = s_ne;
+      prof[static_cast<size_t>(FRAME) * 32 + 29] = V;
+      prof[static_cast<size_t>(FRAME) * 32 + 30] = s_ncand;
+      prof[static_cast<size_t>(FRAME) * 32 + 31] = ~0ull;  // (marks a close-first frame for print_prof)
+    }
+    return;
+  }
   {
     // the adjacent bricks sit in at most five stencil rows ((dy, dz) in the half stencil with |dy|, |dz| <= 1): work item =
     // (brick, one of these rows), P consecutive lanes per brick (round 2 gave every brick eight lanes, three of them idle);
@@ -2230,12 +2665,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   uint8_t* st_cand = reinterpret_cast<uint8_t*>(st_box + 6 * LB_ST_ROWS);
   ClusterRec* table = table_all + static_cast<size_t>(FRAME) * g.vox_cap;  // (the hit list that lived here is dead)
   CandMember* cands = cand_all + static_cast<size_t>(FRAME) * g.vox_cap;
-  auto is_cand = [&](uint32_t close, uint32_t size, const int* box) {
-    int ext_ok = 1;
-    for (int a = 0; a < 3; a++)
-      ext_ok &= (static_cast<float>(box[3 + a] - box[a]) * g.leaf[a] <= up.cand_max_extent);
-    return !close && static_cast<int>(size) >= up.min_points && ext_ok;
-  };
   {
     const uint32_t nc = min(s_nh, static_cast<uint32_t>(LB_ST_ROWS));
     for (uint32_t c = tid; c < nc; c += FR_THREADS)

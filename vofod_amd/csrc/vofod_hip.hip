@@ -292,6 +292,7 @@ struct Workspace
   PackedLite* d_lite = nullptr;
   PackedLite* h_lite = nullptr;  // pinned
   bool lite = false;  // the batch in this workspace was read back through the lite slots (no debug output asked for)
+  int close_first = 0;  // k_frame_lds: 1 = cluster the far voxels only (read-only batches), 2 = the same with labels for the far-only debug view
   bool dtail = false;  // ... or its classification tail ran on the device (kernels_tail.h): only detection records come back
   vtd::TailCluster* d_tailc = nullptr;
   vtd::FrameDets* d_dets = nullptr;
@@ -1371,7 +1372,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
         {
           KLAUNCH(h, k_slab_cuts, dim3(n), dim3(1024), g, bp, ws.d_hdrs, ws.sa, ws.pt_cap, ws.fs, ws.ref_lattice, n_slabs);
           KLAUNCH(h, k_frame_lds<true>, dim3(n * n_slabs), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
-                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, n_slabs);
+                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, n_slabs, 0);
           KLAUNCH(h, k_slab_merge, dim3(n), dim3(SM_THREADS), g, ws.d_hdrs, ws.va, ws.d_table, ws.fs, n, n_slabs, *up_tables);
           KLAUNCH(h, k_slab_gather, dim3(n * n_slabs), dim3(SG_THREADS), g, ws.d_hdrs, ws.va, ws.d_labels, ws.d_cand, ws.fs, n, n_slabs);
           if (d_prof)
@@ -1383,7 +1384,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           return VOFOD_OK;
         }
         KLAUNCH(h, k_frame_lds<false>, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose,
-                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, n, 1u);
+                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, n, 1u,
+                (up_tables && mapclose) ? ws.close_first : 0);
         ws.finalize_fused = up_tables && mapclose;
         if (d_prof)
           if (const int pr = print_prof(0, n); pr != VOFOD_OK)
@@ -1881,6 +1883,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   const bool frame_path = ws.frame_fused;  // brick-first frame kernel: the global occupancy bitmaps are not touched at all
   const bool bitmap_was_clean = ws.bitmap_clean;
   const bool keep_dirty = frame_path || (ws.slab_bitmap && g.sparse_prefix);
+  // Read-only batches cluster close first (k_frame_lds): only the far clusters are ever used (vofod_nodelet.cpp:946-963).  The
+  // debug view of ALL clusters keeps the full clustering; dbg[0].far_only asks for the production path's view instead.
+  // VOFOD_CLOSE_FIRST=0: the full clustering everywhere.
+  static const bool close_first_on = !(std::getenv("VOFOD_CLOSE_FIRST") && std::atoi(std::getenv("VOFOD_CLOSE_FIRST")) == 0);
+  const bool dbg_far_only = dbg && dbg[0].far_only;
+  ws.close_first = (close_first_on && use_dilated) ? (dbg ? (dbg_far_only ? 2 : 0) : 1) : 0;
   r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr,
                      (keep_dirty && no_update) ? &up : nullptr);
   if (r != VOFOD_OK)
@@ -2447,8 +2455,19 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       d.n_bg_voxels = h->n_bg_voxels;
       d.background_pts_sufficient = h->background_pts_sufficient;
       d.sure_background_sufficient = h->sure_background_sufficient;
+      // far-only view (dbg[0].far_only): what the production path of a read-only batch computes - the far clusters, and labels
+      // for their voxels only.  A frame that went through the full clustering all the same (no dilated image, more pure-far
+      // bricks than the close-first path takes, VOFOD_CLOSE_FIRST=0) is cut down to that view here.
+      const bool far_view = dbg[0].far_only != 0;
+      uint32_t n_shown = hdr.C;
+      if (far_view && !hdr.far_only)
+      {
+        n_shown = 0;
+        for (uint32_t c = 0; c < hdr.C; c++)
+          n_shown += T.cl[c].rec.close ? 0u : 1u;
+      }
       d.n_weighted = hdr.V;
-      d.n_clusters = hdr.C;
+      d.n_clusters = n_shown;
       if ((d.weighted || d.labels) && d.weighted_cap < hdr.V)
         ret = VOFOD_ERR_CAPACITY;
       else
@@ -2456,17 +2475,32 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
         if (d.weighted && hdr.V)
           HIPCHK(hipMemcpy(d.weighted, ws.va.pts + static_cast<size_t>(f) * ws.vox_cap, sizeof(float4) * hdr.V, hipMemcpyDeviceToHost));
         if (d.labels && hdr.V)
+        {
           HIPCHK(hipMemcpy(d.labels, ws.d_labels + static_cast<size_t>(f) * ws.vox_cap, sizeof(uint32_t) * hdr.V, hipMemcpyDeviceToHost));
+          if (far_view && !hdr.far_only)
+          {
+            std::vector<uint32_t> far_roots;
+            for (uint32_t c = 0; c < hdr.C; c++)
+              if (!T.cl[c].rec.close)
+                far_roots.push_back(T.cl[c].rec.root);
+            std::sort(far_roots.begin(), far_roots.end());
+            for (uint32_t v = 0; v < hdr.V; v++)
+              if (!std::binary_search(far_roots.begin(), far_roots.end(), d.labels[v]))
+                d.labels[v] = CF_LABEL_NONE;
+          }
+        }
       }
       if (d.clusters)
       {
-        if (d.clusters_cap < hdr.C)
+        if (d.clusters_cap < n_shown)
           ret = VOFOD_ERR_CAPACITY;
         else
-          for (uint32_t c = 0; c < hdr.C; c++)
+          for (uint32_t c = 0, c_out = 0; c < hdr.C; c++)
           {
             const HostCluster& hc = T.cl[c];
-            vofod_cluster_info& ci = d.clusters[c];
+            if (far_view && hc.rec.close)
+              continue;
+            vofod_cluster_info& ci = d.clusters[c_out++];
             ci.first_member = hc.rec.root;
             ci.n_points = hc.rec.size;
             ci.is_close = hc.rec.close;

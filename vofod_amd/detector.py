@@ -203,7 +203,9 @@ class VoFOD:
         out = dets[: n_out.value].copy()
         return (out, self._dbg_dict(dbg, bufs)) if debug else out
 
-    def process_batch(self, scans: Sequence[ScanData], tfs: np.ndarray, debug: bool = False, det_cap: int = 4096, clusters_cap: int | None = None):
+    def process_batch(self, scans: Sequence[ScanData], tfs: np.ndarray, debug: bool = False, det_cap: int = 4096, clusters_cap: int | None = None, far_only: bool = False):
+        """`far_only` (with `debug`): the view of the production path of read-only batches, which clusters close first - the
+        cluster table lists the far clusters only, labels are capi.LABEL_NONE outside them (include/vofod.h)."""
         n = len(scans)
         arr = (capi.Scan * n)(*[s.as_c() for s in scans])
         tfa = np.ascontiguousarray(tfs, dtype=np.float32).reshape(n, 12)
@@ -216,6 +218,7 @@ class VoFOD:
             dbgs = (capi.ScanDebug * n)()
             for f in range(n):
                 d, b = self._mk_dbg(scans[f].width * scans[f].height, clusters_cap)
+                d.far_only = 1 if far_only else 0
                 dbgs[f] = d
                 bufs.append(b)
         st = self.lib.process_batch(self.h, arr, capi.ptr(tfa), n, capi.ptr(dets), det_cap, capi.ptr(per), C.byref(n_out), dbgs)
