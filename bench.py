@@ -280,6 +280,9 @@ def main():
         # per-frame statistics for the algorithmic-bytes model B = 12*N + 40*V
         _, dbg = det.process_scan(scans[0], tfs[0], flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
         V = len(dbg["weighted"])
+        # ... and for the bytes the close-first path really has to move: the voxels of the far clusters (the only ones clustered)
+        _, _, dbg_far = det.process_batch(scans[:4], tfs[:4], debug=True, far_only=True)
+        V_far = float(np.mean([int((g["labels"] != capi.LABEL_NONE).sum()) for g in dbg_far]))
         out = {
             "metric": "LiDAR frames/sec (131k-pt OS1-128) at 1/2/4/8 MI355X + HBM roofline %",
             "value": frames / dt,
@@ -362,15 +365,16 @@ def main():
         if world == 1 and args.host_input_steps > 0:
             out["host_input"] = host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w)
         if not args.no_profile_pass:
-            out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F)
+            out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F, V_far)
             # the same bytes over the pipelined step time of this rank (kernels of consecutive batches overlap: the step is
             # shorter than the sum of its kernels)
-            pb = out["roofline"]["path"]["alg_bytes_per_batch"]
-            out["roofline"]["path"]["pipelined"] = {
-                "us_per_batch": 1e3 * out["ms_per_step"],
-                "GBps": pb / (1e-3 * out["ms_per_step"]) / 1e9,
-                "frac": pb / (1e-3 * out["ms_per_step"]) / 1e9 / HBM_PEAK_GBS,
-            }
+            for key in ("path", "path_moved"):
+                pb = out["roofline"][key]["alg_bytes_per_batch"]
+                out["roofline"][key]["pipelined"] = {
+                    "us_per_batch": 1e3 * out["ms_per_step"],
+                    "GBps": pb / (1e-3 * out["ms_per_step"]) / 1e9,
+                    "frac": pb / (1e-3 * out["ms_per_step"]) / 1e9 / HBM_PEAK_GBS,
+                }
         if args.cpu_baseline_scans > 0:
             out["cpu_baseline"] = cpu_baseline(args, det, host_scans)
     sync()
@@ -421,7 +425,7 @@ def host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w):
     }
 
 
-def profile_pass(lib, det, scans, tfs, n_pts, V, F):
+def profile_pass(lib, det, scans, tfs, n_pts, V, F, V_far=0.0):
     """Per-kernel device time measured with HIP events on the library's own stream (vofod_profile_*)."""
     from vofod_amd import capi
 
@@ -447,8 +451,11 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
         "k_key1<false>": 12.0 * n_pts * F,
         "k_key2<true>": 12.0 * n_pts * F,    # brick codes: the second read of the same columns (counted again here, once in the path total)
         "k_key2<false>": 12.0 * n_pts * F,
-        "k_frame_lds<false>": 40.0 * V * F,  # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
-        "k_frame_lds<true>": 40.0 * V * F,
+        "k_frame_lds_full<false>": 40.0 * V * F,  # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
+        "k_frame_lds_full<true>": 40.0 * V * F,
+        # close first (round 4): the weighted cloud out 16*V, one bit of the dilated map image per voxel, and the clustering's
+        # 16 + 4 + 4 bytes only for the voxels of the far clusters - what this kernel HAS to move, not the contract's 40*V
+        "k_frame_lds_far": (16.0 * V + V / 8.0 + 24.0 * V_far) * F,
         # general path (single scans, fallbacks)
         "k_setbits": 12.0 * n_pts * F,
         "k_key": 12.0 * n_pts * F,
@@ -511,6 +518,18 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F):
             "GBps": (12.0 * n_pts + 40.0 * V) * F / (path_us * 1e-6) / 1e9 if path_us else 0.0,
             "frac": (12.0 * n_pts + 40.0 * V) * F / (path_us * 1e-6) / 1e9 / HBM_PEAK_GBS if path_us else 0.0,
         },
+    }
+    # The contract's B prices a clustering of ALL voxels.  Read-only batches cluster close first: the background is never
+    # clustered at all, so the bytes this path must really move are fewer - both are reported, the dominant kernel's `frac`
+    # above is priced on the latter (VERDICT r3 "honesty rule").
+    moved = (12.0 * n_pts + 16.0 * V + V / 8.0 + 24.0 * V_far) * F
+    roofline["path_moved"] = {
+        "what": "bytes the close-first path has to move: 12*N in, 16*V weighted cloud out, V/8 close bits, 24 B per voxel of a far cluster (V_far)",
+        "voxels_in_far_clusters_per_frame": V_far,
+        "alg_bytes_per_batch": moved,
+        "device_us_per_batch": path_us,
+        "GBps": moved / (path_us * 1e-6) / 1e9 if path_us else 0.0,
+        "frac": moved / (path_us * 1e-6) / 1e9 / HBM_PEAK_GBS if path_us else 0.0,
     }
     return roofline, kernels
 

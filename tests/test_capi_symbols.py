@@ -66,8 +66,9 @@ def test_bench_byte_model_names_the_kernels_of_the_batched_path():
     priced = set(re.findall(r'"(k_[a-z0-9_]+)', table))
     driver = (root / "vofod_amd" / "csrc" / "vofod_hip.hip").read_text()
     launched = set(re.findall(r"KLAUNCH(?:_LDS)?\(h, (?:vk::)?(k_[a-z0-9_]+)", driver))
-    streaming = {k for k in launched if k in ("k_key1", "k_key2", "k_bbox", "k_frame_lds")}
-    assert streaming == {"k_key1", "k_key2", "k_bbox", "k_frame_lds"}
+    names = ("k_key1", "k_key2", "k_bbox", "k_frame_lds_full", "k_frame_lds_far")
+    streaming = {k for k in launched if k in names}
+    assert streaming == set(names)
     assert streaming <= priced, streaming - priced
     prefixes = bench[bench.index("path_prefixes = ("):]
     prefixes = prefixes[: prefixes.index(")")]

@@ -873,6 +873,7 @@ int vofod_reset(vofod_handle* h)
   h->sure_background_sufficient = false;
   h->background_pts_sufficient = false;
   h->last_detection_id = 0;
+  h->cf_off = false;
   return r;
 }
 
@@ -1061,7 +1062,9 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
     size_t got = 0;
     int r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
                            n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
-    if (r == CCL_RETRY_STATUS)  // a frame beyond the LDS capacities of k_frame_lds: this batch once more, on the global kernels
+    // a frame beyond the capacities of the frame kernel: this batch once more - with the full clustering when the close-first
+    // kernel gave up (a cold map), on the global kernels when the LDS image did; the two can follow each other
+    for (int attempt = 0; attempt < 2 && r == CCL_RETRY_STATUS; attempt++)
       r = process_frames(h, h->ws, FRAMES_SYNC, scans + base, tfs + 12 * base, m, VOFOD_SCAN_NO_MAP_UPDATE, out ? out + total : nullptr, total < cap ? cap - total : 0,
                          n_out_per_frame ? n_out_per_frame + base : nullptr, &got, dbg ? dbg + base : nullptr);
     for (size_t i = total; i < std::min(total + got, cap); i++)
@@ -1120,9 +1123,10 @@ int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_
     return VOFOD_ERR_NOT_PENDING;
   *n_out = 0;
   int r = process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);
-  if (r == CCL_RETRY_STATUS)
+  for (int attempt = 0; attempt < 2 && r == CCL_RETRY_STATUS; attempt++)
   {
-    // a frame beyond the LDS capacities of k_frame_lds: the batch is enqueued again (global-memory clustering) from the submitted descriptors
+    // a frame beyond the capacities of the frame kernel: the batch is enqueued again from the submitted descriptors - with the
+    // full clustering when the close-first kernel gave up (a cold map), with the global-memory clustering when the LDS image did
     r = process_frames(h, w, FRAMES_LAUNCH, w.job_scans.data(), w.job_tfs.data(), w.job_n, VOFOD_SCAN_NO_MAP_UPDATE, nullptr, 0, nullptr, nullptr, nullptr);
     if (r == VOFOD_OK)
       r = process_frames(h, w, FRAMES_COLLECT, nullptr, nullptr, 0, VOFOD_SCAN_NO_MAP_UPDATE, out, cap, n_out_per_frame, n_out, nullptr);

@@ -28,6 +28,7 @@ constexpr int LB_WIN = 7;             // widest x-window: reach of 3 bricks
 #endif
 constexpr int LB_ST_ROWS = VOFOD_LB_ST_ROWS;  // components per frame whose statistics are gathered in LDS (36 B each); the rest use global atomics
 constexpr int32_t CCL_RETRY_STATUS = 1000;  // internal FrameHdr::status, never returned through the C-ABI
+constexpr int32_t CF_RETRY_STATUS = 1001;   // internal: more pure-far bricks than the close-first frame kernel takes (a cold map): the batch runs again with the full clustering
 
 struct LbRow
 {

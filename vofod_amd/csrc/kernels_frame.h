@@ -33,9 +33,6 @@ namespace vk
 {
 
 constexpr int FR_THREADS = 1024;
-#ifndef FR_VGPRS
-#define FR_VGPRS 112  /* 4 waves per SIMD x 112 leave 64 registers per lane and SIMD: one guest wave of k_key1 / k_explore beside a frame workgroup */
-#endif
 #ifndef FR_WRITE_BACK_DEF
 #define FR_WRITE_BACK_DEF 1
 #endif
@@ -628,8 +625,12 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
 // results to a slot of its own (n_src + blockIdx.x).  Every edge of the frame's voxel graph lies inside one slab + halo, and a
 // halo voxel is the same voxel as an own voxel of the next slab: k_slab_merge joins the slabs' components through those twins,
 // interleaves the slabs' voxel lists plane by plane into the frame's key order and writes the frame's records to slot f.
-template <bool SLABS>
-__global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS))) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
+// CFM (round 4): 1 = the close-first instantiation - the clustering phases D-E are replaced by the few steps around the
+// pure-far bricks (see behind phase 3a) and the full clustering's code is not in the kernel at all (it set the register
+// budget); a frame beyond its capacity raises CF_RETRY_STATUS and the host runs the batch again with CFM = 0, the kernel of
+// rounds 2-3.
+template <bool SLABS, int CFM>
+__global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
                                                          VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
                                                          const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
                                                          const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,
@@ -1166,14 +1167,10 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
   // Behind the emission: edges and unions around those few bricks only (tens to hundreds per frame instead of ~5 000).
   // Same member lists, sizes, smallest members, hence the same candidates and detections as the full clustering; that one
   // stays for the debug view of ALL clusters, for slabs, and for a frame with more than CF_MAX pure-far bricks (a cold map).
-  bool cf = false;
-  if constexpr (!SLABS)
+  constexpr bool cf = CFM != 0;
+  static_assert(!(SLABS && CFM), "slabs of a frame are clustered in full (their halo voxels have to be labelled)");
+  if constexpr (cf)
   {
-#ifdef CF_BISECT3
-    if (false)
-#else
-    if (close_first && mapclose)
-#endif
     {
       constexpr int NPT = LB_MAX / FR_THREADS;
       const bool mapk_ok = s_mapk[3] != 0;
@@ -1299,7 +1296,16 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
         }
       }
       __syncthreads();
-      cf = s_npf <= static_cast<uint32_t>(CF_MAX);
+      if (s_npf > static_cast<uint32_t>(CF_MAX))
+      {
+        if (tid == 0)
+        {
+          h.status = CF_RETRY_STATUS;  // (a cold map: nearly every brick is pure far) the batch takes the full clustering
+          h.n_bricks = s_npf;
+          h.V = 0;
+        }
+        return;
+      }
     }
   }
   FR_STAMP(15);
@@ -1751,7 +1757,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
   if (tid == 0)
     h.V = V;
   __syncthreads();
-  if (cf)
+  if constexpr (cf)
   {
     for (uint32_t k = tid; k < s_npf; k += FR_THREADS)
     {
@@ -1832,19 +1838,36 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
       ext_ok &= (static_cast<float>(box[3 + a] - box[a]) * g.leaf[a] <= up.cand_max_extent);
     return !close && static_cast<int>(size) >= up.min_points && ext_ok;
   };
-#ifdef CF_BISECT4
-  if (false)
-#else
-  if (cf)
-#endif
+  if constexpr (cf)
   {
     // ---- close first, continued: edges and unions around the pure-far bricks (list entry k <-> thread k from F-b on).
-    // F-a: work item = (pure-far brick, row of the half stencil, direction), as phase D-a2 of the full clustering.  A neighbour
-    // brick with a close voxel taints the entry (both directions: the neighbour is in nobody's list); a pure-far neighbour
-    // is joined (forward direction only: the pair is seen from its base brick).  Octant matrices first, the exact ball test
-    // (FLANN's float expression on the tolerance's boundary) for what they leave open.
+    // Work item = (pure-far brick, row of the half stencil, direction), as phase D-a2 of the full clustering: a thread's items
+    // share row and direction.  A neighbour brick that holds a close voxel TAINTS the entry; a pure-far neighbour is joined.
+    //   F-a1  adjacent bricks (|d| <= 1 brick), every entry, both directions for taints, forward only for unions (the pair is
+    //         seen from its base brick): nearly every pure-far brick next to the ground sheet or a wall is tainted here;
+    //   F-a2  bricks two apart, around the entries still untainted, both directions for both kinds (the partner may be tainted
+    //         and sit this pass out; a pair of two tainted entries has nothing left to decide);
+    //   F-a3  the pairs the octant matrices left open, if they can still change anything: the exact ball test (FLANN's float
+    //         expression on the tolerance's boundary).
     const uint32_t n_pf = s_npf;
     auto tainted = [&](uint32_t k) -> bool { return ((*reinterpret_cast<volatile uint32_t*>(&s_taint[k >> 5]) >> (k & 31u)) & 1u) != 0u; };
+    auto join = [&](uint32_t ka, uint32_t kb) {
+      uint32_t ra = lb_find(s_pfpar, ka), rb = lb_find(s_pfpar, kb);
+      while (ra != rb)  // hook the larger root under the smaller
+      {
+        if (ra < rb)
+        {
+          const uint32_t tmp = ra;
+          ra = rb;
+          rb = tmp;
+        }
+        const uint32_t old = lb_cas16(s_pfpar, ra, ra, rb);
+        if (old == ra)
+          break;
+        ra = old;
+      }
+    };
+    constexpr uint32_t CF_OPEN_UNION = 1u << 23;  // open pair: k | t2 << 10 | kind
     {
       const uint32_t items = n_pf * 32u;
       const int row = (tid >> 1) & 15, back = tid & 1;
@@ -1852,77 +1875,94 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
       uint32_t valid, axis, near;
       unsigned long long ov;
       load_row(row, ddy, ddz, valid, axis, near, ov);
-      uint32_t slots = valid;
+      uint32_t slots_near = valid & near, slots_far = valid & ~near;
       if (back)
       {
-        uint32_t rev = 0;  // the neighbour is the pair's base brick: it sees this brick at (-dx, ddy, ddz), i.e. slot 2R - s
+        uint32_t rn = 0, rf = 0;  // the neighbour is the pair's base brick: it sees this brick at (-dx, ddy, ddz), i.e. slot 2R - s
         for (int sl = 0; sl <= 2 * R; sl++)
-          rev |= ((valid >> (2 * R - sl)) & 1u) << sl;
-        slots = rev;
-      }
-      if (slots)
-        for (uint32_t it = tid; it < items; it += FR_THREADS)
         {
-          const uint32_t k = it >> 5;
-          const uint32_t t = s_pf[k];
-          const uint32_t xa = s_xyz[t];
-          const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
-          const int ny = by + (back ? -ddy : ddy), nz = bz + (back ? -ddz : ddz);
-          if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
-            continue;
-          uint32_t raw, nb0;
-          int shw;
-          uint32_t win = window(bx, ny, nz, raw, nb0, shw) & slots;
-          while (win)
+          rn |= ((slots_near >> (2 * R - sl)) & 1u) << sl;
+          rf |= ((slots_far >> (2 * R - sl)) & 1u) << sl;
+        }
+        slots_near = rn;
+        slots_far = rf;
+      }
+      for (int pass = 0; pass < 2; pass++)
+      {
+        const uint32_t slots = pass == 0 ? slots_near : slots_far;
+        if (slots)
+          for (uint32_t it = tid; it < items; it += FR_THREADS)
           {
-            const int sl = __ffs(static_cast<int>(win)) - 1;
-            win &= win - 1;
-            const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
-            const uint32_t k2 = s_pfidx[t2];
-            const bool other_close = k2 == 0xffffu;
-            if (other_close)
+            const uint32_t k = it >> 5;
+            if (pass == 1 && tainted(k))
+              continue;
+            const uint32_t t = s_pf[k];
+            const uint32_t xa = s_xyz[t];
+            const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
+            const int ny = by + (back ? -ddy : ddy), nz = bz + (back ? -ddz : ddz);
+            if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
+              continue;
+            uint32_t raw, nb0;
+            int shw;
+            uint32_t win = window(bx, ny, nz, raw, nb0, shw) & slots;
+            while (win)
             {
-              if (tainted(k))
+              const int sl = __ffs(static_cast<int>(win)) - 1;
+              win &= win - 1;
+              const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+              const uint32_t k2 = s_pfidx[t2];
+              const uint32_t xb = s_xyz[t2];
+              const bool other_close = k2 == 0xffffu;
+              if (!other_close && ((pass == 0 && back) || lb_ld16(s_pfpar, k) == lb_ld16(s_pfpar, k2)))
                 continue;
-            }
-            else if (back || lb_find(s_pfpar, k) == lb_find(s_pfpar, k2))
-              continue;
-            const uint32_t xb = s_xyz[t2];
-            const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
-            const uint32_t A8 = (back ? xb : xa) >> 24, B8 = (back ? xa : xb) >> 24;  // (the matrices are indexed base brick x brick at the offset)
-            bool conn = lb_octtest(s_tab.oct[2 * o], A8, B8);
-#ifndef CF_BISECT1
-            if (!conn && lb_octtest(s_tab.oct[2 * o + 1], A8, B8))
-#else
-            if (false)
-#endif
-              conn = lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, fr_bx(xb) - bx, fr_by(xb) - by, fr_bz(xb) - bz);
-            if (!conn)
-              continue;
-            if (other_close)
-              atomicOr(&s_taint[k >> 5], 1u << (k & 31u));
-            else
-            {
-              uint32_t ra = lb_find(s_pfpar, k), rb = lb_find(s_pfpar, k2);
-              while (ra != rb)  // hook the larger root under the smaller
+              const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
+              const uint32_t A8 = (back ? xb : xa) >> 24, B8 = (back ? xa : xb) >> 24;  // (the matrices are indexed base brick x brick at the offset)
+              if (lb_octtest(s_tab.oct[2 * o], A8, B8))
               {
-                if (ra < rb)
-                {
-                  const uint32_t tmp = ra;
-                  ra = rb;
-                  rb = tmp;
-                }
-                const uint32_t old = lb_cas16(s_pfpar, ra, ra, rb);
-                if (old == ra)
-                  break;
-                ra = old;
+                if (other_close)
+                  atomicOr(&s_taint[k >> 5], 1u << (k & 31u));
+                else
+                  join(k, k2);
+              }
+              else if (lb_octtest(s_tab.oct[2 * o + 1], A8, B8))
+              {
+                const uint32_t pos = atomicAdd(&s_no, 1u);
+                if (pos < hcap)
+                  hits[pos] = k | (t2 << 10) | (other_close ? 0u : CF_OPEN_UNION);
               }
             }
           }
+        __syncthreads();
+      }
+    }
+    FR_STAMP(8);
+    {
+      const uint32_t no = min(s_no, hcap);
+      for (uint32_t i = tid; i < no; i += FR_THREADS)
+      {
+        const uint32_t e = hits[i];
+        const uint32_t k = e & 1023u, t2 = (e >> 10) & 8191u;
+        const uint32_t k2 = s_pfidx[t2];
+        if (e & CF_OPEN_UNION)
+        {
+          if ((tainted(k) && tainted(k2)) || lb_find(s_pfpar, k) == lb_find(s_pfpar, k2))
+            continue;
         }
+        else if (tainted(k))
+          continue;
+        const uint32_t t = s_pf[k];
+        const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
+        const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
+        if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, fr_bx(xb) - bx, fr_by(xb) - by, fr_bz(xb) - bz))
+          continue;
+        if (e & CF_OPEN_UNION)
+          join(k, k2);
+        else
+          atomicOr(&s_taint[k >> 5], 1u << (k & 31u));
+      }
     }
     __syncthreads();  // (the bitmap is dead from here on: its storage holds the components' accumulators, indexed by the root's list index)
-    FR_STAMP(8);
+    FR_STAMP(9);
     uint32_t* a_size = reinterpret_cast<uint32_t*>(s_bb);
     uint32_t* a_min = a_size + CF_MAX;
     int* a_box = reinterpret_cast<int*>(a_min + CF_MAX);
@@ -1979,7 +2019,7 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
         atomicOr(&s_troot[root >> 5], 1u << (root & 31u));
     }
     __syncthreads();
-    FR_STAMP(9);
+    FR_STAMP(10);
     // F-c: the surviving components ARE far_clusters_indices of vofod_nodelet.cpp:746: their records (close = 0) make the frame's
     // cluster table, the voxels of the candidates among them (enough points, small enough to pass max_size) the member list
     ClusterRec* table = table_all + static_cast<size_t>(FRAME) * g.vox_cap;
@@ -2005,12 +2045,8 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
       for (uint32_t v = tid; v < V; v += FR_THREADS)
         labels[v] = CF_LABEL_NONE;
     __syncthreads();
-    FR_STAMP(10);
-#ifdef CF_BISECT2
-    if (false)
-#else
+    FR_STAMP(11);
     if (surv && (a_cand[root] || close_first == 2))
-#endif
     {
       const bool cand = a_cand[root] != 0;
       const uint32_t label = a_min[root];
@@ -2040,7 +2076,6 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
       h.n_bricks = n;
       h.far_only = 1u;
     }
-    FR_STAMP(11);
     FR_STAMP(12);
     FR_STAMP(13);
     if (prof && tid == 0)
@@ -2788,6 +2823,11 @@ __global__ __launch_bounds__(FR_THREADS) __attribute__((amdgpu_num_vgpr(FR_VGPRS
     h.n_bricks = n;
 #undef FR_STAMP
 }
+
+// the instantiations under names without a comma (the launch macro records the kernel's name as written)
+template <bool SLABS>
+constexpr auto k_frame_lds_full = &k_frame_lds<SLABS, 0>;  // voxelise + cluster everything (debug view, slabs, cold maps, map-updating callers)
+constexpr auto k_frame_lds_far = &k_frame_lds<false, 1>;   // voxelise + cluster the far voxels only (read-only batches)
 
 // ---- slab mode, before the frame kernel: where to cut a frame ------------------------------------------------------------
 // One workgroup per frame: histogram of the frame's (solid) points over the brick rows of its lattice, cuts balanced by point

@@ -481,6 +481,11 @@ struct HostCluster
 struct vofod_handle
 {
   unsigned long long *d_prof_slab = nullptr, *d_prof_ccl = nullptr;  // stamp buffers of the VOFOD_LDS_PROF diagnostics
+  // A frame of a batch held more pure-far bricks than the close-first frame kernel takes (a cold map: nothing is "close"): the
+  // batch ran again with the full clustering, and so do the following ones - until the map has gained background voxels
+  // (nVoxelsOver well above the count at the overflow) or was reset.
+  bool cf_off = false;
+  uint64_t cf_off_bg = 0;
   bool lds_ccl_off = false;  // a frame of the batch just collected overflowed the LDS kernels: the NEXT launch (its re-run) takes the global-memory kernels, then the flag drops
   std::mutex mtx;
   vofod_static_params sp{};
@@ -1345,6 +1350,17 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
             if (byd.empty())
               break;
             const uint32_t f = byd[q].second;
+            if (t[32 * f + 31] == ~0ull)
+            {
+              // a close-first frame: its own phases behind the emission
+              auto us = [&](int a, int b) { return (t[32 * f + b] - t[32 * f + a]) * 0.01; };
+              std::fprintf(stderr,
+                           "[k_frame_lds_far] frame %u: %.1f us | keys %llu V %llu bricks %llu pure-far bricks %llu far clusters %llu candidate members %llu | bits %.1f prefix %.1f words %.1f closebits %.1f count "
+                           "%.1f rank-a/b %.1f rank-c %.1f emit %.1f extras %.1f near+far %.1f open %.1f stats %.1f table %.1f members %.1f\n",
+                           f, byd[q].first, t[32 * f + 27], t[32 * f + 29], t[32 * f + 26], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30], us(0, 1), us(1, 2), us(2, 3), us(3, 15), us(15, 14), us(14, 4), us(4, 5),
+                           us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 13));
+              continue;
+            }
             std::fprintf(stderr, "[k_frame_lds] frame %u: %.1f us | keys %llu V %llu bricks %llu extras %llu hits %llu open %llu surviving %llu |", f, byd[q].first, t[32 * f + 27], t[32 * f + 29],
                          t[32 * f + 26], t[32 * f + 28], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30]);
             for (int i = 0; i < 13; i++)
@@ -1371,7 +1387,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
         if (n_slabs >= 2)
         {
           KLAUNCH(h, k_slab_cuts, dim3(n), dim3(1024), g, bp, ws.d_hdrs, ws.sa, ws.pt_cap, ws.fs, ws.ref_lattice, n_slabs);
-          KLAUNCH(h, k_frame_lds<true>, dim3(n * n_slabs), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
+          KLAUNCH(h, k_frame_lds_full<true>, dim3(n * n_slabs), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
                   mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, n_slabs, 0);
           KLAUNCH(h, k_slab_merge, dim3(n), dim3(SM_THREADS), g, ws.d_hdrs, ws.va, ws.d_table, ws.fs, n, n_slabs, *up_tables);
           KLAUNCH(h, k_slab_gather, dim3(n * n_slabs), dim3(SG_THREADS), g, ws.d_hdrs, ws.va, ws.d_labels, ws.d_cand, ws.fs, n, n_slabs);
@@ -1383,9 +1399,13 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           HIPCHK(hipGetLastError());
           return VOFOD_OK;
         }
-        KLAUNCH(h, k_frame_lds<false>, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose,
-                h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, n, 1u,
-                (up_tables && mapclose) ? ws.close_first : 0);
+        if (up_tables && mapclose && ws.close_first)  // read-only batches: cluster the far voxels only (the close-first instantiation)
+          KLAUNCH(h, k_frame_lds_far, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
+                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, 1u, ws.close_first);
+        else
+          KLAUNCH(h, k_frame_lds_full<false>, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
+                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, n,
+                  1u, 0);
         ws.finalize_fused = up_tables && mapclose;
         if (d_prof)
           if (const int pr = print_prof(0, n); pr != VOFOD_OK)
@@ -1888,7 +1908,9 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // VOFOD_CLOSE_FIRST=0: the full clustering everywhere.
   static const bool close_first_on = !(std::getenv("VOFOD_CLOSE_FIRST") && std::atoi(std::getenv("VOFOD_CLOSE_FIRST")) == 0);
   const bool dbg_far_only = dbg && dbg[0].far_only;
-  ws.close_first = (close_first_on && use_dilated) ? (dbg ? (dbg_far_only ? 2 : 0) : 1) : 0;
+  if (h->cf_off && (h->n_bg_voxels > h->cf_off_bg + h->cf_off_bg / 4 + 1000 || h->n_bg_voxels < h->cf_off_bg))
+    h->cf_off = false;  // the map has changed a lot since: try the close-first kernel again
+  ws.close_first = (close_first_on && use_dilated && !h->cf_off) ? (dbg ? (dbg_far_only ? 2 : 0) : 1) : 0;
   r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr,
                      (keep_dirty && no_update) ? &up : nullptr);
   if (r != VOFOD_OK)
@@ -2076,6 +2098,17 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   }
   if (h->n_bg_voxels > h->background_min_sufficient_pts)  // :716-721
     h->background_pts_sufficient = true;
+  for (uint32_t f = 0; f < n; f++)
+    if (ws.h_packed[f].hdr.status == CF_RETRY_STATUS)
+    {
+      // a frame with more pure-far bricks than the close-first kernel takes: nothing of this batch was used; the caller runs
+      // it again (same descriptors, staged columns kept) with the full clustering
+      h->cf_off = true;
+      h->cf_off_bg = h->n_bg_voxels;
+      ws.rerun = true;
+      ws.job_n = n;
+      return CCL_RETRY_STATUS;
+    }
   if (!no_update)
   {
     h->detection_its++;  // :949
