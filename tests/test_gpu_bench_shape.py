@@ -107,7 +107,8 @@ def test_device_tail_at_the_bench_shape_with_many_targets(oracle, hip):
     names = _profiled_kernels(lib, dev)
     lib.profile_enable(dev.h, 0)
     if os.environ.get("VOFOD_DEVICE_TAIL") != "0" and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK"):
-        assert "k_tail_prep" in names and "k_explore" in names and "k_tail_finish" in names, names
+        # close-first batches: the fused tail; VOFOD_CLOSE_FIRST=0 (full clustering): the three tail kernels of rounds 2-3
+        assert "k_tail_far" in names or ("k_tail_prep" in names and "k_explore" in names and "k_tail_finish" in names), names
     id0 = got["id"][0]
     got = got.copy()
     got["id"] -= id0

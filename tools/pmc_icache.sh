@@ -4,6 +4,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-ic}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+# the library keeps a dozen streams busy: bench.py asks for 16 hardware queues, but under rocprofv3 the runtime is initialised
+# before python starts - the variable has to come from this shell
+export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 4 --warmup 1 --inflight 1 --cpu-baseline-scans 0 --no-profile-pass --host-input-steps 0"
 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/a -- $CMD > $OUT/a.log 2>&1 || { tail -5 $OUT/a.log; exit 1; }

@@ -4,6 +4,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-sq}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+# the library keeps a dozen streams busy: bench.py asks for 16 hardware queues, but under rocprofv3 the runtime is initialised
+# before python starts - the variable has to come from this shell
+export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 4 --warmup 1 --inflight 1 --cpu-baseline-scans 0 --no-profile-pass --host-input-steps 0"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/a -- $CMD > $OUT/a.log 2>&1 || { tail -5 $OUT/a.log; exit 1; }

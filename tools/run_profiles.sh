@@ -6,6 +6,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# the library keeps a dozen streams busy: bench.py asks for 16 hardware queues, but under rocprofv3 the runtime is initialised
+# before python starts - the variable has to come from this shell
+export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp
 # --inflight 1: one batch at a time, so that a kernel's duration and its counters are its own (in the pipelined default the
 # streaming kernels of batch k+1 run beside the frame kernel of batch k: durations stretch, and the device-wide PMC

@@ -3,6 +3,9 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/trace_${1:-x}
 mkdir -p $OUT
+# the library keeps a dozen streams busy: bench.py asks for 16 hardware queues, but under rocprofv3 the runtime is initialised
+# before python starts - the variable has to come from this shell
+export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 5 --cpu-baseline-scans 0 --no-profile-pass ${BENCH_ARGS:-} > $OUT/log.txt 2>&1 || exit 1
 cd $R && python3 - <<PY

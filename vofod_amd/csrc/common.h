@@ -10,6 +10,8 @@ namespace vk
 constexpr int WAVE = 64;
 constexpr int MAX_STENCIL_ROWS = 4096;  // (2R+1)^2/2 rows for R <= 31 would be 1985; hasCloseTo rows (2d)^2 <= 3969
 constexpr int MAX_R = 31;               // neighbour windows are at most 63 bits wide
+constexpr int TAIL_MAXM = 1024;         // device classification tail: candidate members per frame
+constexpr int TAIL_MAXC = 64;           // ... candidate clusters per frame (one lane each)
 
 // Per-frame launch arguments (host -> device once per call).
 struct FrameArgs
@@ -47,6 +49,7 @@ struct FrameHdr
   uint32_t n_undecided; // voxels whose own map row is empty: k_closefar_sweep tests their whole stencil
   int32_t slab_y0, slab_y1;  // frames split into y-slabs (k_frame_lds<true>): the lattice rows [y0, y1) this slab owns
   uint32_t far_only;         // k_frame_lds clustered close first: the cluster table holds the far clusters only, no labels were written
+  uint32_t n_cand_clusters;  // ... and begins with this many candidate clusters in the canonical order, their members sorted (k_tail_far)
 };
 
 // Parameters constant over a call (passed by value).

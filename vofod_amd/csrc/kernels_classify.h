@@ -53,17 +53,14 @@ struct ExploreParams
 
 __device__ __forceinline__ uint32_t pack_rel(int dx, int dy, int dz) { return static_cast<uint32_t>((dx + 128) | ((dy + 128) << 8) | ((dz + 128) << 16)); }
 
-// one wave (64 threads) per frame with jobs; job_begin[f]..job_end[f] index that frame's jobs in order
-__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin, const uint32_t* __restrict__ job_end,
-                                                const int* __restrict__ members, float* __restrict__ map, unsigned long long* __restrict__ overlay_all,
-                                                uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all,
-                                                uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all)
+// The jobs jb..je of frame slot `slot`, in order, by the calling wave (a 64-thread workgroup); s_float: one byte per job,
+// s_walk: 6 * 32 bytes, both in LDS.  k_explore below and the fused tail of the close-first path (kernels_tail.h) run this.
+__device__ __forceinline__ void explore_frame(const ExploreParams& ep, const MapGeom& mg, const ExploreJob* __restrict__ jobs, const uint32_t jb, const uint32_t je, const int* __restrict__ members,
+                                              float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all,
+                                              uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results,
+                                              uint32_t* __restrict__ visited_all, const uint32_t slot, uint8_t* s_float, uint8_t* s_walk)
 {
-  __shared__ uint8_t s_float[EX_MAX_JOBS];
-  __shared__ uint8_t s_walk[6 * 32];
   const int lane = threadIdx.x;
-  const uint32_t slot = blockIdx.x;
-  const uint32_t jb = job_begin[slot], je = job_end[slot];
   if (jb == je)
     return;
   const uint64_t ovl_words = (mg.n + 63) >> 6;
@@ -361,6 +358,18 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64) void
     if (lane == 0)
       ovl_count_all[slot] = 0;
   }
+}
+
+// one wave (64 threads) per frame with jobs; job_begin[f]..job_end[f] index that frame's jobs in order
+__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64) void k_explore(const ExploreParams ep, const MapGeom mg, const ExploreJob* __restrict__ jobs, const uint32_t* __restrict__ job_begin, const uint32_t* __restrict__ job_end,
+                                                const int* __restrict__ members, float* __restrict__ map, unsigned long long* __restrict__ overlay_all,
+                                                uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all,
+                                                uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all)
+{
+  __shared__ uint8_t s_float[EX_MAX_JOBS];
+  __shared__ uint8_t s_walk[6 * 32];
+  const uint32_t slot = blockIdx.x;
+  explore_frame(ep, mg, jobs, job_begin[slot], job_end[slot], members, map, overlay_all, stack_all, explored_all, touched_all, ovl_list_all, ovl_count_all, results, visited_all, slot, s_float, s_walk);
 }
 
 }  // namespace vc

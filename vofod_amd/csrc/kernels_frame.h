@@ -652,7 +652,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint16_t s_pf[CF_MAX];     // their nodes
   __shared__ uint16_t s_pfpar[CF_MAX];  // union-find over the list's indices
   __shared__ uint32_t s_taint[CF_MAX / 32], s_troot[CF_MAX / 32];  // bit k: list entry k has an edge to a brick with a close voxel / the component rooted at k holds such an entry
-  __shared__ uint32_t s_npf, s_nc, s_ncand;
+  __shared__ uint32_t s_npf, s_nc, s_no2, s_ncand;
   unsigned long long* s_bits64 = s_bb;
   uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
   uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
@@ -726,6 +726,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     s_no = 0;
     s_npf = 0;
     s_nc = 0;
+    s_no2 = 0;
     s_ncand = 0;
   }
   if (tid < CF_MAX / 32)
@@ -2021,14 +2022,53 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     __syncthreads();
     FR_STAMP(10);
     // F-c: the surviving components ARE far_clusters_indices of vofod_nodelet.cpp:746: their records (close = 0) make the frame's
-    // cluster table, the voxels of the candidates among them (enough points, small enough to pass max_size) the member list
+    // cluster table, the voxels of the candidates among them (enough points, small enough to pass max_size) the member list.
+    // Both leave in the order the classification tail wants them (k_tail_far reads them without sorting, without LDS): the
+    // candidates first, in the canonical cluster order (size descending, smallest member ascending: SURVEY H3), their members
+    // cluster by cluster with ascending rank (the order PCL's moment sums run in).  Ordering is by counting: a frame has a
+    // handful of candidates with tens of voxels.  Beyond TAIL_MAXC candidates / TAIL_MAXM members (the tail's capacities: it
+    // hands such a batch to the host) the lists leave unordered.
     ClusterRec* table = table_all + static_cast<size_t>(FRAME) * g.vox_cap;
     CandMember* cands = cand_all + static_cast<size_t>(FRAME) * g.vox_cap;
+    uint16_t* a_ord = reinterpret_cast<uint16_t*>(a_cand + CF_MAX);  // per root: its row of the table
+    uint16_t* c_root = a_ord + CF_MAX;                               // candidate roots in arrival order
+    uint16_t* c_byord = c_root + TAIL_MAXC;                          // ... by canonical order
+    uint32_t* st_key = reinterpret_cast<uint32_t*>(c_byord + TAIL_MAXC);  // members: canonical order of the cluster << 16 | rank
+    static_assert(static_cast<size_t>(CF_MAX) * 35u + 4u * TAIL_MAXC + 4u * TAIL_MAXM <= sizeof(unsigned long long) * FR_BB64, "staging of the close-first path lives in the bitmap's storage");
     const bool surv = live && !((s_troot[root >> 5] >> (root & 31u)) & 1u);
+    bool my_cand = false;
+    uint32_t my_slot = 0;
     if (surv && root == k)
     {
-      const bool cand = is_cand(0u, a_size[k], &a_box[6 * k]);
-      a_cand[k] = cand ? 1 : 0;
+      my_cand = is_cand(0u, a_size[k], &a_box[6 * k]);
+      a_cand[k] = my_cand ? 1 : 0;
+      my_slot = atomicAdd(my_cand ? &s_nc : &s_no2, 1u);
+      if (my_cand && my_slot < static_cast<uint32_t>(TAIL_MAXC))
+        c_root[my_slot] = static_cast<uint16_t>(k);
+    }
+    if (close_first == 2)  // the far-only debug view: a label for every voxel
+      for (uint32_t v = tid; v < V; v += FR_THREADS)
+        labels[v] = CF_LABEL_NONE;
+    __syncthreads();
+    FR_STAMP(11);
+    const uint32_t n_cc = s_nc;  // candidate clusters
+    const bool ordered_c = n_cc <= static_cast<uint32_t>(TAIL_MAXC);
+    if (surv && root == k)
+    {
+      uint32_t row = my_cand ? my_slot : n_cc + my_slot;
+      if (my_cand && ordered_c)
+      {
+        row = 0;
+        const uint32_t sz = a_size[k], mn = a_min[k];
+        for (uint32_t j = 0; j < n_cc; j++)
+        {
+          const uint32_t kj = c_root[j];
+          const uint32_t sj = a_size[kj], mj = a_min[kj];
+          row += (sj > sz || (sj == sz && mj < mn)) ? 1u : 0u;
+        }
+        c_byord[row] = static_cast<uint16_t>(k);
+      }
+      a_ord[k] = static_cast<uint16_t>(min(row, 0xffffu));
       ClusterRec rec;
       rec.root = a_min[k];
       rec.size = a_size[k];
@@ -2038,50 +2078,76 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         rec.imax[a] = a_box[6 * k + 3 + a];
       }
       rec.close = 0u;
-      rec.cand = cand ? 1u : 0u;
-      table[atomicAdd(&s_nc, 1u)] = rec;
+      rec.cand = my_cand ? 1u : 0u;
+      table[row] = rec;
     }
-    if (close_first == 2)  // the far-only debug view: a label for every voxel
-      for (uint32_t v = tid; v < V; v += FR_THREADS)
-        labels[v] = CF_LABEL_NONE;
+    // the candidates' voxels: space first ...
+    const bool writes = surv && (a_cand[root] || close_first == 2);
+    const bool cand_brick = surv && a_cand[root] != 0;
+    uint32_t m_base = 0;
+    if (cand_brick)
+      m_base = atomicAdd(&s_ncand, static_cast<uint32_t>(__popcll(W)));
     __syncthreads();
-    FR_STAMP(11);
-    if (surv && (a_cand[root] || close_first == 2))
+    const uint32_t n_mem = s_ncand;
+    const bool ordered_m = ordered_c && n_mem <= static_cast<uint32_t>(TAIL_MAXM);
+    // ... then the records (unordered lists: straight to their places; ordered: staged as keys first)
+    if (writes)
     {
-      const bool cand = a_cand[root] != 0;
       const uint32_t label = a_min[root];
-      uint32_t pos = cand ? atomicAdd(&s_ncand, static_cast<uint32_t>(__popcll(W))) : 0u;
+      const uint32_t ord = a_ord[root];
+      uint32_t pos = m_base;
       unsigned long long w = W;
       while (w)
       {
         const int p = __ffsll(static_cast<long long>(w)) - 1;
         w &= w - 1;
         const uint32_t rank = rank_of(W, p, M, Q);
-        if (cand)
+        if (cand_brick)
         {
-          CandMember cm;
-          cm.root = label;
-          cm.v = rank;
-          cands[pos++] = cm;
+          if (ordered_m)
+            st_key[pos++] = (ord << 16) | rank;  // (rank < V <= 65535: checked in phase 3b)
+          else
+          {
+            CandMember cm;
+            cm.root = label;
+            cm.v = rank;
+            cands[pos++] = cm;
+          }
         }
         if (close_first == 2)
           labels[rank] = label;
       }
     }
+    if (ordered_m)
+    {
+      __syncthreads();
+      for (uint32_t i = tid; i < n_mem; i += FR_THREADS)
+      {
+        const uint32_t key = st_key[i];
+        uint32_t at = 0;
+        for (uint32_t j = 0; j < n_mem; j++)
+          at += st_key[j] < key ? 1u : 0u;  // (keys are distinct: a voxel has one rank)
+        CandMember cm;
+        cm.root = a_min[c_byord[key >> 16]];
+        cm.v = key & 0xffffu;
+        cands[at] = cm;
+      }
+    }
     __syncthreads();
     if (tid == 0)
     {
-      h.C = s_nc;
-      h.n_cand = s_ncand;
+      h.C = n_cc + s_no2;
+      h.n_cand = n_mem;
       h.n_bricks = n;
       h.far_only = 1u;
+      h.n_cand_clusters = n_cc;
     }
     FR_STAMP(12);
     FR_STAMP(13);
     if (prof && tid == 0)
     {
       prof[static_cast<size_t>(FRAME) * 32 + 24] = n_pf;
-      prof[static_cast<size_t>(FRAME) * 32 + 25] = s_nc;
+      prof[static_cast<size_t>(FRAME) * 32 + 25] = s_nc + s_no2;
       prof[static_cast<size_t>(FRAME) * 32 + 26] = n;
       prof[static_cast<size_t>(FRAME) * 32 + 27] = n_keys;
       prof[static_cast<size_t>(FRAME) * 32 + 28] = s_ne;

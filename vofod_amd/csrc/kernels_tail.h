@@ -25,8 +25,8 @@ namespace vtd
 using namespace vk;
 
 constexpr int TP_THREADS = 256;
-constexpr int TP_MAXM = 1024;  // candidate members per frame
-constexpr int TP_MAXC = 64;    // candidate clusters per frame (one lane each)
+constexpr int TP_MAXM = TAIL_MAXM;  // candidate members per frame
+constexpr int TP_MAXC = TAIL_MAXC;  // candidate clusters per frame (one lane each)
 constexpr int TP_MAXD = 16;    // detections per frame read back
 
 struct TailParams
@@ -272,6 +272,204 @@ __global__ __launch_bounds__(TP_THREADS) void k_tail_prep(const GridParams g, co
     TailCluster e{};
     e.job = -1;
     tailc[f * TP_MAXC + lane] = e;
+  }
+}
+
+// ---- the whole tail of a close-first frame in one kernel, one wave per frame, 256 bytes of LDS (round 4) --------------------------
+// k_frame_lds_far leaves the candidate clusters at the head of the frame's cluster table in the canonical order and their
+// members cluster by cluster with ascending rank: no sorting here, hence no LDS to speak of - the wave fits a CU beside a frame
+// workgroup of the next batch (k_tail_prep's 11 KB had to wait for a CU to come free: 50 us alone, 150-200 us in company, and
+// the three tail kernels of a batch, one after the other on the tail stream, had become the pace of the pipeline).
+// Lane c = candidate cluster c: boxes + gates + explore job as k_tail_prep; then the wave runs the frame's flood fills
+// (explore_frame: the code of k_explore) and writes the detection records as k_tail_finish.
+__global__ __launch_bounds__(64) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
+                                                const CandMember* __restrict__ cand_all, VoxelArrays va_all, const MapGeom mg, const TailParams tp, const vc::ExploreParams ep, vc::ExploreJob* __restrict__ jobs,
+                                                int* __restrict__ members_out, float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all,
+                                                uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all,
+                                                vc::ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all, FrameDets* __restrict__ dets, FrameDets* __restrict__ hout)
+{
+  __shared__ uint8_t s_float[TP_MAXC];
+  __shared__ uint8_t s_walk[6 * 32];
+  const uint32_t f = blockIdx.x;
+  const FrameHdr h = hdrs[f];
+  const int lane = threadIdx.x;
+  FrameDets& out = dets[f];
+  uint32_t fallback = 0;
+  const bool ok = h.status == VOFOD_OK;
+  const uint32_t n_cand = ok ? h.n_cand : 0u;
+  const uint32_t nc_all = ok ? h.n_cand_clusters : 0u;
+  if (n_cand > static_cast<uint32_t>(TP_MAXM))
+    fallback |= TAIL_FB_MEMBERS;
+  if (nc_all > static_cast<uint32_t>(TP_MAXC))
+    fallback |= TAIL_FB_CLUSTERS;
+  const uint32_t nc = fallback ? 0u : nc_all;
+  const bool live = lane < static_cast<int>(nc);
+  const ClusterRec* table = table_all + static_cast<size_t>(f) * g.vox_cap;
+  const CandMember* cands = cand_all + static_cast<size_t>(f) * g.vox_cap;
+  const VoxelArrays va = frame_voxels(va_all, f, g.vox_cap);
+  const FrameArgs& a = args[f];
+  ClusterRec rec{};
+  if (live)
+    rec = table[lane];
+  // the cluster's members: the run behind those of the clusters in front (a candidate's members are all its voxels)
+  uint32_t m_count = live ? rec.size : 0u, m_begin = 0;
+  {
+    uint32_t incl = m_count;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1)
+    {
+      const uint32_t t = __shfl_up(incl, s);
+      if (lane >= s)
+        incl += t;
+    }
+    m_begin = incl - m_count;
+  }
+  bool wants_job = false;
+  vc::ExploreJob job{};
+  TailCluster tc{};
+  tc.job = -1;
+  if (live)
+  {
+    tc.root = rec.root;
+    tc.n_members = m_count;
+    auto get = [&](size_t i, float p[3]) {
+      const float4 q = va.pts[cands[m_begin + i].v];
+      p[0] = q.x;
+      p[1] = q.y;
+      p[2] = q.z;
+    };
+    // classify_cluster :1648-1690: boxes and gates
+    bool pass = m_count > 0 && static_cast<int>(m_count) >= tp.min_points;
+    if (m_count > 0)
+    {
+      const vt::Boxes bx = vt::boxes_of_n(m_count, get);
+      for (int q = 0; q < 3; q++)
+        tc.obb_center[q] = bx.obb_center[q];
+      if (pass)
+      {
+        const float d[3] = {a.tf[3] - bx.obb_center[0], a.tf[7] - bx.obb_center[1], a.tf[11] - bx.obb_center[2]};
+        const double dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        pass = !(dist > tp.max_distance);
+      }
+      float obb_size = 0.0f;
+      if (pass)
+      {
+        const float d[3] = {bx.obb_max[0] - bx.obb_min[0], bx.obb_max[1] - bx.obb_min[1], bx.obb_max[2] - bx.obb_min[2]};
+        obb_size = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        pass = !(obb_size > tp.max_size);
+      }
+      if (pass && tp.latches)  // without the latches the cluster stays "unknown" (:1694, :1719-1722): no detection
+      {
+        wants_job = true;
+        job.frame = f;
+        job.n_members = m_count;
+        job.member_off = f * TP_MAXM + m_begin;
+        job.R = static_cast<int>((obb_size + tp.max_explore) / tp.voxel_size);  // :1696
+        if (job.R > vc::EX_MAX_R || job.R < 0)
+          fallback |= TAIL_FB_RADIUS;
+        const int s3[3] = {mg.sx, mg.sy, mg.sz};
+        for (int q = 0; q < 3; q++)  // getSubmapCopy(aabb, inflate 2) voxel_map.cpp:550-559
+        {
+          const int mn = static_cast<int>(floorf((bx.aabb_min[q] - mg.off[q]) * mg.vs_inv)), mx = static_cast<int>(floorf((bx.aabb_max[q] - mg.off[q]) * mg.vs_inv));
+          job.box_lo[q] = min(max(mn - 2, 0), s3[q] - 1);
+          job.box_hi[q] = min(max(mx + 2, 0), s3[q] - 1);
+        }
+        for (uint32_t i = 0; i < m_count; i++)
+        {
+          float p[3];
+          get(i, p);
+          int* o = members_out + 3 * static_cast<size_t>(job.member_off + i);
+          for (int q = 0; q < 3; q++)
+            o[q] = static_cast<int>(floorf((p[q] - mg.off[q]) * mg.vs_inv));
+        }
+      }
+    }
+  }
+  // jobs in cluster order
+  const unsigned long long jm = __ballot(wants_job);
+  uint32_t n_jobs = __popcll(jm);
+  const uint32_t jb = f * TP_MAXC;
+  if (wants_job)
+  {
+    const uint32_t slot = jb + __popcll(jm & ((1ull << lane) - 1ull));
+    job.result_slot = slot;
+    jobs[slot] = job;
+    tc.job = static_cast<int32_t>(slot);
+  }
+  uint32_t fb_all = fallback;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1)
+    fb_all |= __shfl_xor(fb_all, s);
+  if (fb_all)
+  {
+    if (lane == 0)
+    {
+      out.n = 0;
+      out.fallback = fb_all;
+      out.status = h.status;
+      out.n_jobs = 0;
+      if (hout)
+      {
+        hout[f].n = 0;
+        hout[f].fallback = fb_all;
+        hout[f].status = h.status;
+        hout[f].n_jobs = 0;
+      }
+    }
+    return;
+  }
+  __threadfence_block();
+  __syncthreads();  // the jobs and their members' map voxels are written: the wave reads them back
+  vc::explore_frame(ep, mg, jobs, jb, jb + n_jobs, members_out, map, overlay_all, stack_all, explored_all, touched_all, ovl_list_all, ovl_count_all, results, visited_all, f, s_float, s_walk);
+  __threadfence_block();
+  __syncthreads();
+  // the floating clusters (extractDetections :843-846) in cluster order, as k_tail_finish
+  bool det = false, bad = false;
+  double conf = 0.0;
+  if (tc.job >= 0)
+  {
+    const vc::ExploreResult r = results[tc.job];
+    det = r.floating != 0u;
+    bad = r.overflow != 0u;
+    conf = r.conf_sum;
+  }
+  const unsigned long long dm = __ballot(det), bm = __ballot(bad);
+  const uint32_t n = __popcll(dm);
+  if (det)
+  {
+    const uint32_t pos = __popcll(dm & ((1ull << lane) - 1ull));
+    if (pos < TP_MAXD)
+    {
+      DetRaw d;
+      d.root = tc.root;
+      d.n_points = tc.n_members;
+      for (int q = 0; q < 3; q++)
+        d.center[q] = tc.obb_center[q];
+      d.pad = 0;
+      d.conf_sum = conf;
+      out.d[pos] = d;
+      if (hout)
+        hout[f].d[pos] = d;
+    }
+  }
+  if (lane == 0)
+  {
+    uint32_t fb = 0;
+    if (n > TP_MAXD)
+      fb |= TAIL_FB_DETS;
+    if (bm)
+      fb |= TAIL_FB_EXPLORE;
+    out.n = n;
+    out.fallback = fb;
+    out.status = h.status;
+    out.n_jobs = n_jobs;
+    if (hout)
+    {
+      hout[f].n = n;
+      hout[f].fallback = fb;
+      hout[f].status = h.status;
+      hout[f].n_jobs = n_jobs;
+    }
   }
 }
 

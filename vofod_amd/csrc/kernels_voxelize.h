@@ -160,6 +160,7 @@ __global__ void k_init_hdr(FrameHdr* hdrs, uint32_t* counts2)
     h.n_bricks = 0;
     h.n_undecided = 0;
     h.far_only = 0;
+    h.n_cand_clusters = 0;
   }
 }
 

@@ -292,6 +292,7 @@ struct Workspace
   PackedLite* d_lite = nullptr;
   PackedLite* h_lite = nullptr;  // pinned
   bool lite = false;  // the batch in this workspace was read back through the lite slots (no debug output asked for)
+  bool far_ran = false;  // launch_cluster ran k_frame_lds_far: the cluster table and the member list are in the order k_tail_far reads
   int close_first = 0;  // k_frame_lds: 1 = cluster the far voxels only (read-only batches), 2 = the same with labels for the far-only debug view
   bool dtail = false;  // ... or its classification tail ran on the device (kernels_tail.h): only detection records come back
   vtd::TailCluster* d_tailc = nullptr;
@@ -1299,6 +1300,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
 {
   ws.finalize_fused = false;
   ws.closefar_fused = false;
+  ws.far_ran = false;
   vofod_handle::ClusterTables* ct = nullptr;
   const int rt = cluster_tables(h, g, tol, cmax, &ct);
   if (rt != VOFOD_OK)
@@ -1399,7 +1401,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           HIPCHK(hipGetLastError());
           return VOFOD_OK;
         }
-        if (up_tables && mapclose && ws.close_first)  // read-only batches: cluster the far voxels only (the close-first instantiation)
+        ws.far_ran = up_tables && mapclose && ws.close_first;
+        if (ws.far_ran)  // read-only batches: cluster the far voxels only (the close-first instantiation)
           KLAUNCH(h, k_frame_lds_far, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
                   mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, 1u, ws.close_first);
         else
@@ -2013,12 +2016,19 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ep.ray_score = dp.voxel_map__scores__ray;
     ep.no_update = 1;
     ep.stack_cap = vc::EX_CELLS;
-    KLAUNCH(h, vtd::k_tail_prep, dim3(n), dim3(vtd::TP_THREADS), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, ws.d_tailc,
-            ws.d_dets);
-    KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched, eb.d_ovl_list,
-            eb.d_ovl_count, eb.d_results, eb.d_visited);
-    // the records (135 KB) go straight into the pinned host slots from k_tail_finish: no copy command on any stream (see there)
-    KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets, ws.h_dets_dev);
+    // the records (135 KB) go straight into the pinned host slots from the last tail kernel: no copy command on any stream (see k_tail_finish)
+    if (ws.far_ran && ws.close_first == 1)
+      // close-first frames: ordered lists from the frame kernel, the whole tail in one kernel of one wave per frame
+      KLAUNCH(h, vtd::k_tail_far, dim3(n), dim3(64), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, ep, eb.d_jobs, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
+              eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited, ws.d_dets, ws.h_dets_dev);
+    else
+    {
+      KLAUNCH(h, vtd::k_tail_prep, dim3(n), dim3(vtd::TP_THREADS), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, ws.d_tailc,
+              ws.d_dets);
+      KLAUNCH(h, vc::k_explore, dim3(n), dim3(64), ep, h->mg, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched, eb.d_ovl_list,
+              eb.d_ovl_count, eb.d_results, eb.d_visited);
+      KLAUNCH(h, vtd::k_tail_finish, dim3(n), dim3(64), ws.d_tailc, eb.d_results, ws.d_dets, ws.h_dets_dev);
+    }
     if (own_tail < 0)
       HIPCHK(hipEventRecord(h->ev_explore, h->stream));  // the shared flood-fill buffers are free again
     tail_stream_used = h->stream;
