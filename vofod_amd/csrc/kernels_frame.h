@@ -653,6 +653,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint16_t s_pfpar[CF_MAX];  // union-find over the list's indices
   __shared__ uint32_t s_taint[CF_MAX / 32], s_troot[CF_MAX / 32];  // bit k: list entry k has an edge to a brick with a close voxel / the component rooted at k holds such an entry
   __shared__ uint32_t s_npf, s_nc, s_no2, s_ncand;
+  __shared__ __attribute__((aligned(16))) uint32_t s_cfd[32][4];  // (stencil row, direction) descriptors of the close-first edge passes
+  __shared__ uint8_t s_cfl[2][32];
+  __shared__ uint32_t s_cfn[2];
   unsigned long long* s_bits64 = s_bb;
   uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
   uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
@@ -1869,9 +1872,12 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     };
     constexpr uint32_t CF_OPEN_UNION = 1u << 23;  // open pair: k | t2 << 10 | kind
+    // (row, direction) combinations and their slots: 32 descriptors in LDS, and the lists of those that have adjacent / far slots
+    // at all - the items of a pass are dealt over ALL threads (a thread per (entry, combination); with a fixed combination per
+    // thread, as in D-a2, a third of the threads carried the adjacent pass: 11-19 us of LDS latency chains)
+    if (tid < 32)
     {
-      const uint32_t items = n_pf * 32u;
-      const int row = (tid >> 1) & 15, back = tid & 1;
+      const int row = tid >> 1, back = tid & 1;
       int ddy, ddz;
       uint32_t valid, axis, near;
       unsigned long long ov;
@@ -1887,54 +1893,77 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         }
         slots_near = rn;
         slots_far = rf;
+        ddy = -ddy;
+        ddz = -ddz;
       }
-      for (int pass = 0; pass < 2; pass++)
+      s_cfd[tid][0] = (static_cast<uint32_t>(ddy) & 0xffu) | ((static_cast<uint32_t>(ddz) & 0xffu) << 8) | (slots_near << 16) | (slots_far << 24);
+      s_cfd[tid][1] = static_cast<uint32_t>(back);
+      s_cfd[tid][2] = static_cast<uint32_t>(ov);
+      s_cfd[tid][3] = static_cast<uint32_t>(ov >> 32);
+      const unsigned long long mn = __ballot(slots_near != 0u), mf = __ballot(slots_far != 0u);
+      if (slots_near)
+        s_cfl[0][__popcll(mn & ((1ull << tid) - 1ull))] = static_cast<uint8_t>(tid);
+      if (slots_far)
+        s_cfl[1][__popcll(mf & ((1ull << tid) - 1ull))] = static_cast<uint8_t>(tid);
+      if (tid == 0)
       {
-        const uint32_t slots = pass == 0 ? slots_near : slots_far;
-        if (slots)
-          for (uint32_t it = tid; it < items; it += FR_THREADS)
-          {
-            const uint32_t k = it >> 5;
-            if (pass == 1 && tainted(k))
-              continue;
-            const uint32_t t = s_pf[k];
-            const uint32_t xa = s_xyz[t];
-            const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
-            const int ny = by + (back ? -ddy : ddy), nz = bz + (back ? -ddz : ddz);
-            if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
-              continue;
-            uint32_t raw, nb0;
-            int shw;
-            uint32_t win = window(bx, ny, nz, raw, nb0, shw) & slots;
-            while (win)
-            {
-              const int sl = __ffs(static_cast<int>(win)) - 1;
-              win &= win - 1;
-              const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
-              const uint32_t k2 = s_pfidx[t2];
-              const uint32_t xb = s_xyz[t2];
-              const bool other_close = k2 == 0xffffu;
-              if (!other_close && ((pass == 0 && back) || lb_ld16(s_pfpar, k) == lb_ld16(s_pfpar, k2)))
-                continue;
-              const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
-              const uint32_t A8 = (back ? xb : xa) >> 24, B8 = (back ? xa : xb) >> 24;  // (the matrices are indexed base brick x brick at the offset)
-              if (lb_octtest(s_tab.oct[2 * o], A8, B8))
-              {
-                if (other_close)
-                  atomicOr(&s_taint[k >> 5], 1u << (k & 31u));
-                else
-                  join(k, k2);
-              }
-              else if (lb_octtest(s_tab.oct[2 * o + 1], A8, B8))
-              {
-                const uint32_t pos = atomicAdd(&s_no, 1u);
-                if (pos < hcap)
-                  hits[pos] = k | (t2 << 10) | (other_close ? 0u : CF_OPEN_UNION);
-              }
-            }
-          }
-        __syncthreads();
+        s_cfn[0] = static_cast<uint32_t>(__popcll(mn));
+        s_cfn[1] = static_cast<uint32_t>(__popcll(mf));
       }
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++)
+    {
+      const uint32_t ncmb = s_cfn[pass];
+      const uint32_t items = n_pf * ncmb;
+      const uint32_t inv = ncmb > 1u ? 0xffffffffu / ncmb + 1u : 0u;  // it / ncmb == umulhi(it, ceil(2^32 / ncmb)) for it < 2^32 / ncmb
+      for (uint32_t it = tid; it < items; it += FR_THREADS)
+      {
+        const uint32_t k = ncmb > 1u ? __umulhi(it, inv) : it;
+        if (pass == 1 && tainted(k))
+          continue;
+        const uint4 dsc = *reinterpret_cast<const uint4*>(&s_cfd[s_cfl[pass][it - k * ncmb]][0]);
+        const int ddy = static_cast<int8_t>(dsc.x & 0xffu), ddz = static_cast<int8_t>((dsc.x >> 8) & 0xffu);
+        const uint32_t slots = pass == 0 ? (dsc.x >> 16) & 0xffu : dsc.x >> 24;
+        const bool back = dsc.y != 0u;
+        const unsigned long long ov = static_cast<unsigned long long>(dsc.z) | (static_cast<unsigned long long>(dsc.w) << 32);
+        const uint32_t t = s_pf[k];
+        const uint32_t xa = s_xyz[t];
+        const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
+        const int ny = by + ddy, nz = bz + ddz;  // (the descriptor of a backward combination carries the negated offsets)
+        if (ny < 0 || ny >= nby || nz < 0 || nz >= nbz)
+          continue;
+        uint32_t raw, nb0;
+        int shw;
+        uint32_t win = window(bx, ny, nz, raw, nb0, shw) & slots;
+        while (win)
+        {
+          const int sl = __ffs(static_cast<int>(win)) - 1;
+          win &= win - 1;
+          const uint32_t t2 = nb0 + __popc(raw & ((1u << (sl - shw)) - 1u));
+          const uint32_t k2 = s_pfidx[t2];
+          const uint32_t xb = s_xyz[t2];
+          const bool other_close = k2 == 0xffffu;
+          if (!other_close && ((pass == 0 && back) || lb_ld16(s_pfpar, k) == lb_ld16(s_pfpar, k2)))
+            continue;
+          const uint32_t o = static_cast<uint32_t>(ov >> (8 * (back ? 2 * R - sl : sl))) & 0xffu;
+          const uint32_t A8 = (back ? xb : xa) >> 24, B8 = (back ? xa : xb) >> 24;  // (the matrices are indexed base brick x brick at the offset)
+          if (lb_octtest(s_tab.oct[2 * o], A8, B8))
+          {
+            if (other_close)
+              atomicOr(&s_taint[k >> 5], 1u << (k & 31u));
+            else
+              join(k, k2);
+          }
+          else if (lb_octtest(s_tab.oct[2 * o + 1], A8, B8))
+          {
+            const uint32_t pos = atomicAdd(&s_no, 1u);
+            if (pos < hcap)
+              hits[pos] = k | (t2 << 10) | (other_close ? 0u : CF_OPEN_UNION);
+          }
+        }
+      }
+      __syncthreads();
     }
     FR_STAMP(8);
     {
