@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _rebase(got, want):
     got = got.copy()
     if len(got) and len(want):
-        got["id"] += want["id"][0] - got["id"][0]
+        got["id"] = (got["id"].astype(np.int64) + int(want["id"][0]) - int(got["id"][0])).astype(got["id"].dtype)
     return got
 
 

@@ -13,7 +13,7 @@ import pytest
 from vofod_amd import capi, synth
 from vofod_amd.detector import ScanData, VofodError, cluster, voxel_grid_counted, voxel_grid_weighted
 
-from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair, sync_maps
+from helpers import assert_detections_equal, assert_scan_debug_equal, far_view, make_pair, sync_maps
 
 pytestmark = pytest.mark.gpu
 
@@ -295,13 +295,13 @@ def _dense_scan(sensor, seed, extent, empty=False):
         z = rng.uniform(-2.0, 1.0, n).astype(np.float32)
     return ScanData(x=x, y=y, z=z.copy(), width=w, height=h, stride_bytes=4)
 
-@pytest.mark.parametrize("n_frames,max_batch,want_slabs", [(4, 36, True), (10, 32, True), (6, 6, False)])
-def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch, want_slabs, monkeypatch):
-    """Batches that would leave most CUs idle with one workgroup per frame: every frame is cut into y-slabs (k_frame_lds<true>,
-    one workgroup per slab with a halo, k_slab_merge joins them).  The ground sheet and the buildings span every slab, so the
-    largest component of every frame is stitched across all cuts; an empty and a dense frame ride along.  Everything the
-    debug output carries (weighted cloud, labels, cluster table, detections) equals the oracle's."""
-    monkeypatch.setenv("VOFOD_SLABS_PER_FRAME", "8")  # the slab path is opt-in
+@pytest.mark.parametrize("n_frames,max_batch", [(4, 36), (10, 32), (6, 6)])
+def test_small_batches_with_dense_and_empty_frames(oracle, hip, n_frames, max_batch):
+    """Small batches (one workgroup per frame leaves most CUs idle; round 3 cut such frames into y-slabs, removed in round 4
+    when the close-first kernel halved the frame stage) with and without spare workspace slots: the ground sheet and the
+    buildings form one giant close component, an empty and a dense frame ride along - the dense one beyond the close-first
+    kernel's and the LDS image's capacities, so the batch is run again, twice.  Everything the debug output carries (weighted
+    cloud, labels, cluster table, detections) equals the oracle's, in the full view and in the far-only view."""
     ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=max_batch)
     scene = synth.make_scene(77, n_targets=3)
     ap = synth.apriori_points(scene, 0.25)
@@ -313,15 +313,7 @@ def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch,
     scans[1] = _dense_scan("os1-128", 6, 20.0)             # points all over a 40 m square: many bricks in every slab
     if n_frames > 4:
         scans[3] = _dense_scan("os1-128", 7, 1.0, empty=True)
-    lib = dev.lib
-    lib.profile_enable(dev.h, 1)
     db, pb, gb = dev.process_batch(scans, tfs, debug=True, clusters_cap=65536)
-    names = []
-    if not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK"):
-        buf, ms, calls = (C.c_char * (64 * 96))(), (C.c_double * 96)(), (C.c_uint64 * 96)()
-        n = lib.profile_read(dev.h, buf, ms, calls, 96)
-        names = [buf[64 * i : 64 * i + 64].split(b"\0", 1)[0].decode() for i in range(n)]
-    lib.profile_enable(dev.h, 0)
     da, pa, ga = ref.process_batch(scans, tfs, debug=True, clusters_cap=65536)
     np.testing.assert_array_equal(pb, pa)
     assert_detections_equal(da, db)
@@ -331,8 +323,15 @@ def test_small_batches_split_frames_into_slabs(oracle, hip, n_frames, max_batch,
         except AssertionError as e:
             raise AssertionError(f"frame {k}: {e}") from e
     assert max(len(g["clusters"]) for g in ga) > 20
-    if names and os.environ.get("VOFOD_BRICK_LDS") != "0" and os.environ.get("VOFOD_CCL") != "voxel" and os.environ.get("VOFOD_DILATE") != "0" and os.environ.get("VOFOD_ONEPASS") != "0":  # (the slab path builds on the frame kernel with the single-pass input and the dilated map image)
-        assert ("k_slab_merge" in names) == want_slabs, names
+    # the far-only view: the close-first kernel's own output where a frame fits it, the full clustering cut down otherwise
+    dbf, pbf, gbf = dev.process_batch(scans, tfs, debug=True, clusters_cap=65536, far_only=True)
+    np.testing.assert_array_equal(pbf, pa)
+    assert_detections_equal(da, _rebase_ids(dbf, da))
+    for k, (x, y) in enumerate(zip(ga, gbf)):
+        try:
+            assert_scan_debug_equal(far_view(x), y)
+        except AssertionError as e:
+            raise AssertionError(f"far view, frame {k}: {e}") from e
     # without debug output (device tail) and pipelined: the same detections
     got, per = dev.process_batch(scans, tfs)
     np.testing.assert_array_equal(per, pa)

@@ -26,13 +26,12 @@ def main():
     ap.add_argument("--dyn", action="store_true", help="also randomise dynamic (detection_params.yaml) parameters")
     args = ap.parse_args()
     import vofod_amd
-    from helpers import assert_detections_equal, assert_scan_debug_equal, make_pair
+    from helpers import assert_detections_equal, assert_scan_debug_equal, far_view, make_pair
     from vofod_amd import capi, synth
     from vofod_amd.detector import VofodError
 
     import os
 
-    os.environ.setdefault("VOFOD_SLABS_PER_FRAME", "8")  # the opt-in slab path is part of the sweep (batches with spare slots)
     hip = vofod_amd.library()
     oracle = capi.Library(ROOT / "oracle" / "libvofod_oracle.so", "vofod_oracle_")
     t_end = time.time() + args.seconds
@@ -69,7 +68,7 @@ def main():
                 mask = mask_layout(hip, (rng.random((hh, ww)) < rng.uniform(0.5, 1.0)).astype(np.uint8), ww, hh, rng.integers(0, 16, hh).astype(np.int32))
                 dyn["raycast__min_intensity"] = float(rng.choice([0.0, 100.0, 500.0]))
                 desc += f" calibrated lut+mask, min_intensity {dyn['raycast__min_intensity']}"
-            # spare workspace slots let small batches split their frames into slabs (k_frame_lds<true> + k_slab_merge)
+            # (spare workspace slots: a batch smaller than the handle's workspaces)
             cap_mult = int(rng.choice([1, 3, 4, 9])) if n_batch <= 17 else 1
             desc += f" slots x{cap_mult}"
             ref, dev = make_pair(oracle, hip, sensor, voxel, max_batch=n_batch * cap_mult, lut=lut, mask=mask, **dyn)
@@ -120,11 +119,35 @@ def main():
             assert_detections_equal(da, db)
             for x, y in zip(ga, gb):
                 assert_scan_debug_equal(x, y)
+            # the production path of read-only batches (round 4): close-first clustering + fused tail.  Its far-only view against
+            # the far part of the oracle's full clustering; its detections without debug output, synchronous and pipelined
+            def rebased(d):
+                d = d.copy()
+                if len(d) and len(da):
+                    d["id"] = (d["id"].astype(np.int64) + int(da["id"][0]) - int(d["id"][0])).astype(d["id"].dtype)
+                return d
+
+            dbf, pbf, gbf = dev.process_batch([s.scan for s in scans], tfs, debug=True, far_only=True)
+            np.testing.assert_array_equal(pbf, pa)
+            assert_detections_equal(da, rebased(dbf))
+            for x, y in zip(ga, gbf):
+                assert_scan_debug_equal(far_view(x), y)
+            dc, pc = dev.process_batch([s.scan for s in scans], tfs)
+            np.testing.assert_array_equal(pc, pa)
+            assert_detections_equal(da, rebased(dc))
+            tk = [dev.batch_submit([s.scan for s in scans], tfs) for _ in range(2)]
+            for t in tk:
+                dd, pd = dev.batch_collect(t)
+                np.testing.assert_array_equal(pd, pa)
+                assert_detections_equal(da, rebased(dd))
             # one sequential scan with map update on top
             s = base[0]
             ra, ha = ref.process_scan(s.scan, s.tf, debug=True)
             rb, hb = dev.process_scan(s.scan, s.tf, debug=True)
             assert_scan_debug_equal(ha, hb)
+            if len(ra) and len(rb):  # (the extra batch calls above handed out ids on the HIP side only)
+                rb = rb.copy()
+                rb["id"] = (rb["id"].astype(np.int64) + int(ra["id"][0]) - int(rb["id"][0])).astype(rb["id"].dtype)
             assert_detections_equal(ra, rb)
             np.testing.assert_array_equal(dev.read_map(), ref.read_map())
             # the raycast accumulation of that scan (LUT offsets, mask and intensity gate are inputs of this stage only)

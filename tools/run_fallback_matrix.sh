@@ -2,8 +2,8 @@
 # GPU parity suite under every switch that turns a fast path off (README "Environment switches"); one line per run.
 # Usage on the GPU box: bash tools/run_fallback_matrix.sh [quick]   (quick: the switches of the batched fast path only)
 set -o pipefail
-ALL=("" VOFOD_ONEPASS=0 VOFOD_DEVICE_TAIL=0 VOFOD_LITE=0 VOFOD_SLABS=0 VOFOD_SLAB_EMIT=0 VOFOD_BRICK_LDS=0 VOFOD_DILATE=0 VOFOD_CCL=voxel VOFOD_TWO_CHAINS=0 VOFOD_STAGGER=0 VOFOD_PIPE=ticket "VOFOD_DEVICE_TAIL=0 VOFOD_LITE=0" VOFOD_EXPLORE=host)
-QUICK=(VOFOD_ONEPASS=0 VOFOD_DEVICE_TAIL=0 VOFOD_TWO_CHAINS=0 VOFOD_PIPE=ticket "VOFOD_DEVICE_TAIL=0 VOFOD_LITE=0" VOFOD_BRICK_LDS=0 VOFOD_CCL=voxel)
+ALL=("" VOFOD_CLOSE_FIRST=0 VOFOD_ONEPASS=0 VOFOD_DEVICE_TAIL=0 VOFOD_LITE=0 VOFOD_SLABS=0 VOFOD_SLAB_EMIT=0 VOFOD_BRICK_LDS=0 VOFOD_DILATE=0 VOFOD_CCL=voxel "VOFOD_DEVICE_TAIL=0 VOFOD_LITE=0" "VOFOD_CLOSE_FIRST=0 VOFOD_DEVICE_TAIL=0" VOFOD_EXPLORE=host)
+QUICK=(VOFOD_CLOSE_FIRST=0 VOFOD_ONEPASS=0 VOFOD_DEVICE_TAIL=0 "VOFOD_DEVICE_TAIL=0 VOFOD_LITE=0" VOFOD_BRICK_LDS=0 VOFOD_CCL=voxel)
 if [ "$1" = quick ]; then SW=("${QUICK[@]}"); else SW=("${ALL[@]}"); fi
 for sw in "${SW[@]}"; do
   printf "%-36s " "${sw:-default}"

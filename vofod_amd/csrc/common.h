@@ -47,7 +47,6 @@ struct FrameHdr
   uint32_t need_words;  // bitmap words the lattice needs (reported even when it exceeds the workspace)
   uint32_t n_bricks;    // occupied 4x4x4 bricks (brick-level clustering)
   uint32_t n_undecided; // voxels whose own map row is empty: k_closefar_sweep tests their whole stencil
-  int32_t slab_y0, slab_y1;  // frames split into y-slabs (k_frame_lds<true>): the lattice rows [y0, y1) this slab owns
   uint32_t far_only;         // k_frame_lds clustered close first: the cluster table holds the far clusters only, no labels were written
   uint32_t n_cand_clusters;  // ... and begins with this many candidate clusters in the canonical order, their members sorted (k_tail_far)
 };
@@ -64,7 +63,6 @@ struct GridParams
   uint32_t words_cap;          // bitmap words available per frame
   uint32_t vox_cap;            // voxel records available per frame
   uint32_t n_frames;           // frames covered by the launch
-  uint32_t xcd_map;            // 1: blocks of frame f are dealt to XCD f % 8 (per-frame working set stays in one L2)
   uint32_t sparse_prefix;      // 1: word-prefix entries of all-empty bitmap blocks are not written (brick clustering only)
 };
 

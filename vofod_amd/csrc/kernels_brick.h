@@ -280,108 +280,6 @@ __global__ __launch_bounds__(256) void k_brick_conn(const GridParams g, const Br
   }
 }
 
-// Phase 2 (k_brick_link): one lane per brick merges the brick with all its connected neighbours at once: the
-// representatives of up to LINK_K nodes are chased with independent loads, every non-minimal representative is hooked
-// under the minimum with independent compare-and-swaps, and only the nodes whose hook lost a race are resolved again.
-constexpr int LINK_K = 16;
-__global__ __launch_bounds__(256) void k_brick_link(const GridParams g, const BrickParams bp, const BrickOff* __restrict__ offs, const FrameHdr* hdrs,
-                                                    BrickArrays ba_all, const unsigned long long* __restrict__ conn_all)
-{
-  uint32_t FRAME, BX, GX;
-  if (!frame_block(g, FRAME, BX, GX))
-    return;
-  (void)GX;
-  const FrameHdr& h = hdrs[FRAME];
-  const uint32_t t = BX * blockDim.x + threadIdx.x;
-  if (t >= h.n_bricks)
-    return;
-  const BrickArrays ba = frame_bricks(ba_all, FRAME, bp.bricks_cap, g.vox_cap);
-  unsigned long long mask = conn_all[static_cast<size_t>(FRAME) * g.vox_cap + t];
-  if (!mask)
-    return;
-  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2;
-  const uint32_t b = ba.blist[t];
-  volatile uint32_t* parent = ba.bparent;
-  uint32_t rv = b;
-  while (mask)
-  {
-    uint32_t R[LINK_K + 1], N[LINK_K + 1];
-    int k = 1;
-    R[0] = rv;
-#pragma unroll
-    for (int i = 1; i <= LINK_K; i++)
-    {
-      R[i] = 0xffffffffu;
-      if (mask)
-      {
-        const int o = __ffsll(static_cast<long long>(mask)) - 1;
-        mask &= mask - 1;
-        const BrickOff off = offs[o];
-        R[i] = b + static_cast<uint32_t>((off.dz * nby + off.dy) * nbx + off.dx);
-        k = i + 1;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i <= LINK_K; i++)
-      N[i] = R[i];
-    for (int round = 0; round < 64; round++)
-    {
-      // chase all representatives, independent loads per sweep
-      bool moving = true;
-      while (moving)
-      {
-        moving = false;
-        uint32_t P[LINK_K + 1];
-#pragma unroll
-        for (int i = 0; i <= LINK_K; i++)
-          P[i] = (i < k) ? parent[R[i]] : 0u;
-#pragma unroll
-        for (int i = 0; i <= LINK_K; i++)
-          if (i < k && P[i] != R[i])
-          {
-            R[i] = P[i];
-            moving = true;
-          }
-      }
-      uint32_t m = R[0];
-#pragma unroll
-      for (int i = 1; i <= LINK_K; i++)
-        if (i < k)
-          m = min(m, R[i]);
-      // hook every other representative under the minimum
-      bool retry = false;
-      uint32_t O[LINK_K + 1];
-#pragma unroll
-      for (int i = 0; i <= LINK_K; i++)
-        O[i] = (i < k && R[i] != m) ? atomicCAS(const_cast<uint32_t*>(&parent[R[i]]), R[i], m) : 0xffffffffu;
-#pragma unroll
-      for (int i = 0; i <= LINK_K; i++)
-        if (i < k && R[i] != m)
-        {
-          if (O[i] == R[i] || O[i] == m)
-            R[i] = m;
-          else
-          {
-            R[i] = O[i];  // lost a race: R[i] has a new parent, resolve again
-            retry = true;
-          }
-        }
-      if (!retry)
-        break;
-    }
-    // path compression: every node of this batch now hangs directly under the common representative
-#pragma unroll
-    for (int i = 0; i <= LINK_K; i++)
-      if (i < k && N[i] > R[i])
-        parent[N[i]] = R[i];
-    rv = R[0];
-#pragma unroll
-    for (int i = 1; i <= LINK_K; i++)
-      if (i < k)
-        rv = min(rv, R[i]);
-  }
-}
-
 // Phase 2 alternative (k_brick_link_tr): transitive reduction of the brick graph before any union.  The edge (b,n)
 // is redundant when some brick c with b < c < n is connected to both: (b,c) is among b's own edges and (c,n) is read
 // from c's connectivity mask through pair_idx[o1][o2] = the stencil index of offset(o2) - offset(o1) (or -1).  By

@@ -64,12 +64,7 @@ struct FrameScratch
   unsigned long long* bbsave; // [F][FR_BB64]: the brick bitmap + prefix, parked while their LDS holds the per-voxel point counters
   unsigned long long* nodeA; // [F][LB_MAX][4]: per node, per zz: voxels of the earlier bricks of its brick row, per yy channel (16 bits each);
                              //   bit 63 of [3]: the row began inside the node's 64-node chunk (no carry to add)
-  uint32_t* planes;          // [F][3][FR_PLANES] (slab mode): rank of the first voxel of every z plane, of the plane's first halo voxel, and
-                             //   (k_slab_merge) the rank in the whole frame of the slab's first own voxel of the plane
-  int32_t* cuts;             // [F][FR_SLABS_MAX + 2] (slab mode): lattice rows where the slabs begin, [n_slabs] = end; last: halo thickness
 };
-constexpr int FR_PLANES = 4 * FR_MAX_NBZ;
-constexpr int FR_SLABS_MAX = 8;
 
 // 16-byte load through the global address space (the column pointers come out of a struct in memory: the compiler would
 // otherwise emit flat loads, which also probe the LDS aperture)
@@ -282,6 +277,25 @@ __device__ __forceinline__ void wave_bbox(float (&mn)[3], float (&mx)[3])
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Packed f32 operation of a wave-uniform scalar with a pair of points: op_sel_hi:[0,1] makes the upper lane read the LOW dword
+// of the scalar operand too, so the constant needs no pair of vector registers (round 3's kernel spent 72 of its 778 vector
+// instructions per 8 points on v_mov re-building such pairs: the register budget of a guest wave leaves no room to keep 18 of
+// them).  Every lane rounds like the scalar instruction, as before.
+__device__ __forceinline__ f32x2 pk_mul_s(float c, f32x2 v)
+{
+  f32x2 d;
+  const unsigned long long c64 = __float_as_uint(c);
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(c64), "v"(v));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add_s(float c, f32x2 v)
+{
+  f32x2 d;
+  const unsigned long long c64 = __float_as_uint(c);
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(c64), "v"(v));
+  return d;
+}
+
 // Round 3: the kernel was bound by its vector instructions (~112 executed per point).  Now: the transform and the cell
 // expression work on PAIRS of consecutive points as packed-f32 operations (v_pk_mul_f32 / v_pk_add_f32: every lane of a
 // packed instruction rounds like the scalar one, so the separately rounded se3 association is kept); the bounding box is
@@ -292,11 +306,8 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
 {
 #pragma clang fp contract(off)
   // (2-D grid: blockIdx.y = frame - the frame / block split of a 1-D grid costs two integer divisions per wave, ~7 % of this
-  // kernel's vector instructions; the XCD-aware 1-D mapping of frame_block stays available behind g.xcd_map)
-  uint32_t FRAME = blockIdx.y, BX = blockIdx.x, GX = 0;
-  if (g.xcd_map && !frame_block(g, FRAME, BX, GX))
-    return;
-  (void)GX;
+  // kernel's vector instructions)
+  const uint32_t FRAME = blockIdx.y, BX = blockIdx.x;
   const FrameArgs a = args[FRAME];  // (a copy: the transform stays in scalar registers)
   const uint32_t base_blk = BX * KEY1_THREADS * KEY1_PPT;
   if (base_blk >= a.n)
@@ -310,12 +321,10 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
 #pragma unroll
     for (int q = 0; q < KEY1_PPT / 4; q++)
     {
-      float4 x0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), y0 = x0, z0 = x0;  // (0,0,0) lies inside the exclude box; the index test drops it anyway
-      if (i0 + 4 * q < a.n)
-      {
-        const uint64_t o = (static_cast<uint64_t>(i0) + 4 * q) * 4;
-        x0 = ldg_f4(a.x + o), y0 = ldg_f4(a.y + o), z0 = ldg_f4(a.z + o);
-      }
+      // (a quad behind the cloud's end reads the last quad instead - the number of points is a multiple of 4, and at least 4
+      // here; the index test below drops its points: no conditional load, no registers to clear first)
+      const uint64_t o = static_cast<uint64_t>(min(i0 + 4u * q, a.n - 4u)) * 4;
+      const float4 x0 = ldg_f4(a.x + o), y0 = ldg_f4(a.y + o), z0 = ldg_f4(a.z + o);
       px[4 * q] = x0.x, px[4 * q + 1] = x0.y, px[4 * q + 2] = x0.z, px[4 * q + 3] = x0.w;
       py[4 * q] = y0.x, py[4 * q + 1] = y0.y, py[4 * q + 2] = y0.z, py[4 * q + 3] = y0.w;
       pz[4 * q] = z0.x, pz[4 * q + 1] = z0.y, pz[4 * q + 2] = z0.z, pz[4 * q + 3] = z0.w;
@@ -360,10 +369,7 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
     f32x2 q[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
-    {
-      const f32x2 c0 = {a.tf[4 * r + 0], a.tf[4 * r + 0]}, c1 = {a.tf[4 * r + 1], a.tf[4 * r + 1]}, c2 = {a.tf[4 * r + 2], a.tf[4 * r + 2]}, c3 = {a.tf[4 * r + 3], a.tf[4 * r + 3]};
-      q[r] = c0 * X + (c1 * Y + (c2 * Z + c3));
-    }
+      q[r] = pk_mul_s(a.tf[4 * r + 0], X) + (pk_mul_s(a.tf[4 * r + 1], Y) + pk_add_s(a.tf[4 * r + 3], pk_mul_s(a.tf[4 * r + 2], Z)));
 #pragma unroll
     for (int e = 0; e < 2; e++)
     {
@@ -386,8 +392,7 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
-      const f32x2 off = {rl.off[c], rl.off[c]}, inv = {g.inv[c], g.inv[c]};
-      const f32x2 t = (q[c] - off) * inv;
+      const f32x2 t = pk_mul_s(g.inv[c], pk_add_s(-rl.off[c], q[c]));  // (q - off) * inv: adding the negated offset rounds as the subtraction does
       fl[c][0] = floorf(t[0]);
       fl[c][1] = floorf(t[1]);
       const f32x2 half = {0.5f, 0.5f};
@@ -617,25 +622,17 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
   return o;
 }
 
-// SLABS (round 3): a frame is split over several workgroups.  A batch of fewer frames than the chip has CUs leaves most of
-// them idle under "one workgroup per frame" (32 frames: 7/8 of the chip).  With SLABS the grid holds n_src * n_slabs
-// workgroups; workgroup (f, s) takes the points of frame f whose lattice row y lies in slab s - contiguous ranges of brick
-// rows balanced by point count (every slab workgroup builds the same histogram) - PLUS a halo of the next slab's first rows
-// (tolerance / leaf + 1 cells), voxelises and clusters them exactly as a whole frame (same lattice, same code) and writes its
-// results to a slot of its own (n_src + blockIdx.x).  Every edge of the frame's voxel graph lies inside one slab + halo, and a
-// halo voxel is the same voxel as an own voxel of the next slab: k_slab_merge joins the slabs' components through those twins,
-// interleaves the slabs' voxel lists plane by plane into the frame's key order and writes the frame's records to slot f.
 // CFM (round 4): 1 = the close-first instantiation - the clustering phases D-E are replaced by the few steps around the
 // pure-far bricks (see behind phase 3a) and the full clustering's code is not in the kernel at all (it set the register
 // budget); a frame beyond its capacity raises CF_RETRY_STATUS and the host runs the batch again with CFM = 0, the kernel of
 // rounds 2-3.
-template <bool SLABS, int CFM>
+template <int CFM>
 __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
                                                          VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
                                                          const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
                                                          const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,
                                                          CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof, const RefLattice rl, const FrameArgs* __restrict__ args,
-                                                         uint32_t n_src, uint32_t n_slabs, int close_first)
+                                                         int close_first)
 {
   __shared__ __attribute__((aligned(16))) unsigned long long s_bb[FR_BB64];  // brick-lattice bitmap (bit = linear brick id) + exclusive popcount prefix per
                                                                             // 64-bit word; during the counting / rank phases: one byte counter per voxel
@@ -665,11 +662,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   // the streaming kernels of the next batch run beside this kernel (process_frames' pipeline): this kernel's waves are the
   // critical path and go first wherever both want to issue
   __builtin_amdgcn_s_setprio(FR_WAVE_PRIO);
-  const uint32_t SRC = SLABS ? blockIdx.x / n_slabs : blockIdx.x;    // the frame whose point lists and bounding box are read
-  const uint32_t SLAB = SLABS ? blockIdx.x - SRC * n_slabs : 0u;
-  const uint32_t FRAME = SLABS ? n_src + blockIdx.x : blockIdx.x;    // the slot everything is written to
+  const uint32_t FRAME = blockIdx.x;
+  const uint32_t SRC = FRAME;
   FrameHdr& h = hdrs[FRAME];
-  __shared__ int s_slab[3];  // (slab mode) lattice rows [y0, y1) this workgroup owns, y1h: end of its halo
   __shared__ int s_mapk[4];  // lattice cell -> map cell offsets, [3]: valid (see below)
   __shared__ __attribute__((aligned(16))) uint32_t s_near[5][4];  // descriptors of the stencil rows that hold adjacent bricks (phase D)
   __shared__ uint32_t s_near_n;
@@ -679,11 +674,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     // left in the header - one kernel less between the streaming kernel and this one (k_grid, a launch gap of the pipeline)
     if (threadIdx.x == 0)
     {
-      if constexpr (SLABS)
-      {
-        h = hdrs[SRC];  // (V = C = n_cand = 0, status OK: k_init_hdr; bounding box: k_key1)
-        h.slab_y0 = h.slab_y1 = 0;
-      }
       grid_of_frame(g, h);
     }
     __syncthreads();
@@ -735,7 +725,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   if (tid < CF_MAX / 32)
     s_taint[tid] = s_troot[tid] = 0u;
   __syncthreads();
-  const uint32_t* codes = sa.keys + static_cast<size_t>(FRAME) * pt_cap;      // the list the passes 3a / 3b read (slab mode: this slab's codes)
+  const uint32_t* codes = sa.keys + static_cast<size_t>(FRAME) * pt_cap;      // the list the passes 3a / 3b read
   const uint32_t* codes_src = sa.keys + static_cast<size_t>(SRC) * pt_cap;    // k_key1's list of the whole frame
   uint32_t* extras_g = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
   constexpr int KPT = 16;  // consecutive codes per thread and round: points of one ring that share a voxel / brick are merged in registers
@@ -819,8 +809,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     return cell_code(static_cast<int>(r & 2047u) - sh0, static_cast<int>((r >> 11) & 2047u) - sh1, static_cast<int>(r >> 22) - sh2);
   };
   // the fragile points: exact expression with the frame's own offset (voxel_grid_weighted.cpp:131-136); their codes follow
-  // the reference cells in the list.  `lo` / `hi`: the lattice rows kept (slab mode), `dst0`: where their codes go.
-  auto fragile_points = [&](int lo, int hi, uint32_t dst0, uint32_t* counter) {
+  // the reference cells in the list.
+  auto fragile_points = [&]() {
+    const uint32_t dst0 = n_ref;
     const uint32_t* frag = sa.extras + static_cast<size_t>(SRC) * pt_cap;
     const FrameArgs& fa = args[SRC];
     for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
@@ -835,20 +826,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], hoff1), g.inv[1])));
       const int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], hoff2), g.inv[2])));
       uint32_t cd = cell_code(k0, k1, k2);
-      if constexpr (SLABS)
-      {
-        // (the row of the cell the code stands for: an aliased cell is judged by its aliased row)
-        if (cd != FR_CODE_NONE)
-        {
-          const int row = static_cast<int>(4u * ((cd >> 15) & 511u) + ((cd >> 2) & 3u));
-          if (row < lo || row >= hi)
-            cd = FR_CODE_NONE;
-        }
-        if (cd != FR_CODE_NONE)
-          codes_w[dst0 + atomicAdd(counter, 1u)] = cd;
-      }
-      else
-        codes_w[dst0 + i] = cd;
+      codes_w[dst0 + i] = cd;
       if (cd != FR_CODE_NONE)
       {
         const uint32_t L = brick_lin(cd >> 6);
@@ -856,111 +834,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
   };
-  if constexpr (!SLABS)
-  {
-    if (rl.on)
-      fragile_points(0, 0, n_ref, nullptr);
-  }
+  if (rl.on)
+    fragile_points();
   // ---- 1: the occupied bricks.  Consecutive codes of a thread mostly share their brick: one LDS atomic per run.
-  if constexpr (SLABS)
-  {
-    // -- slab boundaries: k_slab_cuts balanced them over the frame's points (lattice rows [y0, y1) own, [y1, y1h) halo)
-    if (tid == 0)
-    {
-      const int* cuts = reinterpret_cast<const int*>(fs.cuts) + static_cast<size_t>(SRC) * (FR_SLABS_MAX + 2);
-      const int halo_cells = cuts[FR_SLABS_MAX + 1];
-      const int y0 = cuts[SLAB], y1 = cuts[SLAB + 1];
-      s_slab[0] = y0;
-      s_slab[1] = y1;
-      s_slab[2] = y1 >= dv1 ? y1 : min(y1 + halo_cells, dv1);  // no halo behind the lattice's last row
-      h.slab_y0 = y0;
-      h.slab_y1 = y1;
-    }
-    __syncthreads();
-    const int y_lo = s_slab[0], y_hi = s_slab[2];
-    // -- this slab's codes: converted, compacted in list order into the slab's own list, marked in the bitmap
-    uint32_t n_out = 0;
-    for (uint32_t base0 = 0; base0 < n_ref; base0 += FR_THREADS * KPT)
-    {
-      const uint32_t base = base0 + tid * KPT;
-      uint32_t c[KPT];
-      if (vec_ok && base + KPT <= n_ref)
-      {
-#pragma unroll
-        for (int q = 0; q < KPT / 4; q++)
-        {
-          const uint4 a = *reinterpret_cast<const uint4*>(codes_src + base + 4 * q);
-          c[4 * q] = a.x, c[4 * q + 1] = a.y, c[4 * q + 2] = a.z, c[4 * q + 3] = a.w;
-        }
-      }
-      else
-      {
-#pragma unroll
-        for (int u = 0; u < KPT; u++)
-          c[u] = base + u < n_ref ? codes_src[base + u] : FR_CODE_NONE;
-      }
-      uint32_t cnt = 0;
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-      {
-        if (c[u] != FR_CODE_NONE)
-        {
-          const int k1 = static_cast<int>((c[u] >> 11) & 2047u) - sh1;
-          c[u] = (k1 >= y_lo && k1 < y_hi) ? ref_code(c[u]) : FR_CODE_NONE;
-        }
-        cnt += c[u] != FR_CODE_NONE ? 1u : 0u;
-      }
-      const uint32_t incl = wave_incl_scan(cnt);
-      if (lane == 63)
-        s_wsum[wave] = incl;
-      __syncthreads();
-      uint32_t off = incl - cnt, total = 0;
-      for (int w = 0; w < FR_THREADS / 64; w++)
-      {
-        const uint32_t x = s_wsum[w];
-        off += w < wave ? x : 0u;
-        total += x;
-      }
-      __syncthreads();
-      uint32_t* out = codes_w + n_out + off;
-      uint32_t cur = FR_CODE_NONE;
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-      {
-        if (c[u] == FR_CODE_NONE)
-          continue;
-        *out++ = c[u];
-        const uint32_t b = c[u] >> 6;
-        if (b != cur)
-        {
-          if (cur != FR_CODE_NONE)
-          {
-            const uint32_t L = brick_lin(cur);
-            atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
-          }
-          cur = b;
-        }
-      }
-      if (cur != FR_CODE_NONE)
-      {
-        const uint32_t L = brick_lin(cur);
-        atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
-      }
-      n_out += total;
-    }
-    if (tid == 0)
-      s_nn = 0;  // (reset again before its use in phase D)
-    __syncthreads();
-    fragile_points(y_lo, y_hi, n_out, &s_nn);
-    __syncthreads();
-    n_keys = n_out + s_nn;
-    __syncthreads();
-    if (tid == 0)
-      s_nn = 0;
-    if (n_keys == 0)
-      return;  // an empty slab: V = C = 0 in its header
-  }
-  else
   {
     uint32_t c[KPT], cn[KPT];
     const uint32_t n_pass1 = rl.on ? n_ref : n_keys;
@@ -1099,7 +975,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     {
       if (base + FR_THREADS * KPT < n_keys)
         load_codes(base + FR_THREADS * KPT, cn);
-      if constexpr (!FR_WRITE_BACK && !SLABS)
+      if constexpr (!FR_WRITE_BACK)
       {
         if (rl.on)  // pass 1 kept the reference cells in the list (the fragile points' codes behind them are brick codes already)
         {
@@ -1170,9 +1046,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   // Here: which bricks are pure far (one lookup of the dilated image per occupied lattice row of a brick, until the first hit).
   // Behind the emission: edges and unions around those few bricks only (tens to hundreds per frame instead of ~5 000).
   // Same member lists, sizes, smallest members, hence the same candidates and detections as the full clustering; that one
-  // stays for the debug view of ALL clusters, for slabs, and for a frame with more than CF_MAX pure-far bricks (a cold map).
+  // stays for the debug view of ALL clusters and for a frame with more than CF_MAX pure-far bricks (a cold map).
   constexpr bool cf = CFM != 0;
-  static_assert(!(SLABS && CFM), "slabs of a frame are clustered in full (their halo voxels have to be labelled)");
   if constexpr (cf)
   {
     {
@@ -1525,11 +1400,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const uint32_t r = bz * nby + by;
       r_out = r;
       zz_out = zz;
-      if constexpr (SLABS)
-      {
-        if (static_cast<int>(by) < (s_slab[0] >> 2) || static_cast<int>(4u * by) >= s_slab[2])
-          return 0xffffffffu;  // a brick row outside the slab and its halo: empty, no look-up
-      }
       const uint32_t b0 = r * nbx, b1 = b0 + nbx;
       const uint32_t n0 = fr_node(pk_bits, pk_pre, b0);
       const uint32_t n1 = b1 < nb_total ? fr_node(pk_bits, pk_pre, b1) : n;
@@ -1582,15 +1452,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     {
       uint32_t plane = plane0, by = by0;
       auto place = [&](uint32_t sv, uint32_t r, uint32_t zz) {
-        if constexpr (SLABS)
-        {
-          // rank of the first voxel of every z plane, and of the plane's first voxel behind the slab's own rows (its halo)
-          uint32_t* planes = fs.planes + static_cast<size_t>(FRAME) * 3 * FR_PLANES;
-          if (by == 0)
-            planes[plane] = run;
-          if (by == static_cast<uint32_t>(s_slab[1] >> 2))
-            planes[FR_PLANES + plane] = run;
-        }
         if (sv != 0xffffffffu)
         {
           rowQ[static_cast<size_t>(r) * 4 + zz] = run;
@@ -1694,7 +1555,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       va.pts[rank] = pt;  // (through L2 on purpose: it merges the scattered 16-byte records into lines; non-temporal stores cost 21 % of the throughput)
       if (!cf)  // (the label pass of the full clustering finds a voxel's brick here; the close-first path has no such pass)
         reinterpret_cast<uint16_t*>(va.bb)[rank] = static_cast<uint16_t>(i);  // (node < LB_MAX: 16 bits; the general kernels keep 32-bit brick codes here)
-      if (!write_tables || SLABS)
+      if (!write_tables)
         va.key[rank] = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
       if (first && !cf)
         bmin_g[i] = rank;  // bit order inside a brick is the key order: the lowest bit is the brick's first voxel
@@ -2565,13 +2426,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       my_root[r] = root;
       my_w[r] = s_word[i];
       my_min[r] = bmin_g[i];
-      if constexpr (SLABS)
-      {
-        // a component's label and size count its OWN voxels only (cuts run between brick rows: a brick is own or halo as a
-        // whole); the halo's voxels are counted by the next slab
-        if (s_slab[1] < dv1 && fr_by(s_xyz[i]) >= (s_slab[1] >> 2))
-          my_min[r] = 0xffffffffu;
-      }
     }
   }
   __syncthreads();  // roots and words are in registers: flatten the forest, turn the words into the minima
@@ -2628,7 +2482,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           st_box[6 * c + 3 + a] = static_cast<int>(0x80000000u);
         }
       }
-      else if (!SLABS)  // (slab mode gives such a frame up below; a slab component's label may be "no own voxel")
+      else
       {
         atomicExch(&va.csize[label], 0u);
         atomicExch(&va.cclose[label], 0u);
@@ -2641,18 +2495,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     }
   }
   __syncthreads();
-  if constexpr (SLABS)
-  {
-    if (s_nh > static_cast<uint32_t>(LB_ST_ROWS))  // the merge kernel addresses a slab's components by their table row
-    {
-      if (tid == 0)
-      {
-        h.status = CCL_RETRY_STATUS;
-        h.V = 0;
-      }
-      return;
-    }
-  }
 #pragma unroll
   for (int r = 0; r < LB_MAX / FR_THREADS; r++)
   {
@@ -2675,11 +2517,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     const int lo[3] = {4 * bx + __ffs(static_cast<int>(ox)) - 1, 4 * by + __ffs(static_cast<int>(oy)) - 1, 4 * bz + __ffs(static_cast<int>(oz)) - 1};
     const int hi[3] = {4 * bx + 31 - __clz(static_cast<int>(ox)), 4 * by + 31 - __clz(static_cast<int>(oy)), 4 * bz + 31 - __clz(static_cast<int>(oz))};
     uint32_t cnt = __popcll(W);
-    if constexpr (SLABS)
-    {
-      if (s_slab[1] < dv1 && by >= (s_slab[1] >> 2))
-        cnt = 0u;  // halo brick: counted by the slab that owns it
-    }
     bool hit = false;
     if (live && mapclose && !(c < LB_ST_ROWS ? st_close[c] : 0u))
     {
@@ -2800,13 +2637,11 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     for (uint32_t c = tid; c < nc; c += FR_THREADS)
     {
       const uint32_t label = st_label[c];
-      if constexpr (!SLABS)  // (per-label slots serve the unfused consumers; a slab component's label may be "no own voxel")
-      {
-        va.csize[label] = st_cnt[c];
-        va.cclose[label] = st_close[c];
-        for (int a = 0; a < 6; a++)
-          va.cbox[6 * label + a] = st_box[6 * c + a];
-      }
+      // (per-label slots serve the unfused consumers)
+      va.csize[label] = st_cnt[c];
+      va.cclose[label] = st_close[c];
+      for (int a = 0; a < 6; a++)
+        va.cbox[6 * label + a] = st_box[6 * c + a];
       if (write_tables)
       {
         const bool cand = is_cand(st_close[c], st_cnt[c], &st_box[6 * c]);
@@ -2821,14 +2656,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         }
         rec.close = st_close[c];
         rec.cand = cand ? 1u : 0u;
-        if constexpr (SLABS)
-          table[c] = rec;  // row = component index: the merge kernel finds a voxel's component through it
-        else
-          table[atomicAdd(&h.C, 1u)] = rec;
+        table[atomicAdd(&h.C, 1u)] = rec;
       }
     }
-    if (SLABS && tid == 0)
-      h.C = nc;
   }
   __syncthreads();
   FR_STAMP(12);
@@ -2855,12 +2685,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         const uint32_t node = nodev[u];
         const uint32_t root = s_par[node];
         label = s_cmin[root];
-        if constexpr (SLABS)
-        {
-          // the slab's voxels are relabelled by k_slab_merge: all it needs is the voxel's component (table row)
-          reinterpret_cast<uint16_t*>(va.bb)[v] = s_cidx[root];
-          continue;
-        }
         labels[v] = label;
         if (write_tables)
         {
@@ -2892,7 +2716,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           }
         }
       }
-      if (write_tables && !SLABS)
+      if (write_tables)
       {
         const unsigned long long m = __ballot(cand);
         if (m)
@@ -2920,541 +2744,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
 }
 
 // the instantiations under names without a comma (the launch macro records the kernel's name as written)
-template <bool SLABS>
-constexpr auto k_frame_lds_full = &k_frame_lds<SLABS, 0>;  // voxelise + cluster everything (debug view, slabs, cold maps, map-updating callers)
-constexpr auto k_frame_lds_far = &k_frame_lds<false, 1>;   // voxelise + cluster the far voxels only (read-only batches)
-
-// ---- slab mode, before the frame kernel: where to cut a frame ------------------------------------------------------------
-// One workgroup per frame: histogram of the frame's (solid) points over the brick rows of its lattice, cuts balanced by point
-// count with a minimum thickness of one halo (tolerance / leaf + 1 cells: a lattice edge spans less), at brick-row granularity.
-__global__ __launch_bounds__(1024) void k_slab_cuts(const GridParams g, const BrickParams bp, const FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, FrameScratch fs, const RefLattice rl,
-                                                    uint32_t n_slabs)
-{
-  __shared__ uint32_t s_hist[512];
-  __shared__ FrameHdr s_h;
-  const uint32_t F = blockIdx.x;
-  const int tid = threadIdx.x;
-  int32_t* cuts = fs.cuts + static_cast<size_t>(F) * (FR_SLABS_MAX + 2);
-  if (tid == 0)
-  {
-    s_h = hdrs[F];
-    grid_of_frame(g, s_h);  // (the slab workgroups compute the same lattice from the same bounding box)
-  }
-  for (int i = tid; i < 512; i += 1024)
-    s_hist[i] = 0u;
-  __syncthreads();
-  const int dv1 = s_h.div_b[1], nby = (dv1 + 3) >> 2;
-  const int halo_cells = static_cast<int>(floorf(__fmul_rn(sqrtf(bp.r2), g.inv[1]))) + 1;
-  if (s_h.n_in == 0 || nby > 512)
-  {
-    if (tid <= static_cast<int>(n_slabs))
-      cuts[tid] = tid == 0 ? 0 : dv1;  // everything in slab 0 (an empty frame, or one the frame kernel refuses anyway)
-    if (tid == 0)
-      cuts[FR_SLABS_MAX + 1] = halo_cells;
-    return;
-  }
-  const int sh1 = static_cast<int>(rint((static_cast<double>(s_h.offset[1]) - static_cast<double>(rl.off[1])) * static_cast<double>(g.inv[1])));
-  const uint32_t n_ref = sa.counts[2 * F];
-  const uint32_t* codes = sa.keys + static_cast<size_t>(F) * pt_cap;
-  constexpr int KPT = 8;
-  const bool vec_ok = (reinterpret_cast<uintptr_t>(codes) & 15u) == 0u;
-  for (uint32_t base = tid * KPT; base < n_ref; base += 1024 * KPT)
-  {
-    uint32_t cc[KPT];
-    if (vec_ok && base + KPT <= n_ref)
-    {
-      const uint4 a = *reinterpret_cast<const uint4*>(codes + base), b = *reinterpret_cast<const uint4*>(codes + base + 4);
-      cc[0] = a.x, cc[1] = a.y, cc[2] = a.z, cc[3] = a.w, cc[4] = b.x, cc[5] = b.y, cc[6] = b.z, cc[7] = b.w;
-    }
-    else
-    {
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-        cc[u] = base + u < n_ref ? codes[base + u] : FR_CODE_NONE;
-    }
-    uint32_t cur = 0xffffffffu, cnt = 0;
-#pragma unroll
-    for (int u = 0; u < KPT; u++)
-    {
-      const uint32_t c = cc[u];
-      const int k1 = static_cast<int>((c >> 11) & 2047u) - sh1;
-      if (c == FR_CODE_NONE || static_cast<uint32_t>(k1) >= static_cast<uint32_t>(dv1))
-        continue;
-      const uint32_t row = static_cast<uint32_t>(k1) >> 2;
-      if (row != cur)
-      {
-        if (cnt)
-          atomicAdd(&s_hist[cur], cnt);
-        cur = row;
-        cnt = 0;
-      }
-      cnt++;
-    }
-    if (cnt)
-      atomicAdd(&s_hist[cur], cnt);
-  }
-  __syncthreads();
-  if (tid == 0)
-  {
-    uint32_t total = 0;
-    for (int r = 0; r < nby; r++)
-      total += s_hist[r];
-    const int min_rows = (halo_cells + 3) >> 2;
-    uint32_t acc = 0;
-    int row = 0, prev_b = 0;
-    cuts[0] = 0;
-    for (uint32_t k = 1; k <= n_slabs; k++)
-    {
-      int b = nby;
-      if (k < n_slabs)
-      {
-        const uint32_t target = static_cast<uint32_t>((static_cast<unsigned long long>(total) * k) / n_slabs);
-        while (row < nby && acc < target)
-          acc += s_hist[row++];
-        b = min(max(row, prev_b + min_rows), nby);
-      }
-      cuts[k] = min(4 * b, dv1);
-      prev_b = b;
-    }
-    cuts[FR_SLABS_MAX + 1] = halo_cells;
-  }
-}
-
-// ---- slab mode, after the frame kernel: the frame out of its slabs ---------------------------------------------------------
-// Slab s of frame f lives in slot n_src + f * n_slabs + s: voxel records in the key order of the frame's lattice restricted to
-// the slab's rows [y0, y1 + halo), a component index per voxel (16 bits, = row of the slab's cluster table), the cluster table
-// (own voxels / lattice box / close flag / smallest own rank per component), plane tables (fs.planes).
-//   * ranks: inside a z plane the slabs' own rows follow each other (y is the middle key digit), so the frame's voxel list
-//     is, plane by plane, slab 0's own voxels of the plane, slab 1's, ...: a voxel's rank = base of (plane, slab) + its offset;
-//   * components: the halo voxels of slab s in plane z are the first voxels of slab s + 1 in that plane, in the same order
-//     (same points, same lattice): the k-th halo voxel and the k-th own voxel are twins, their components are one;
-//   * labels: the smallest rank of a merged component's own voxels (the oracle's canonical label); sizes: own voxels;
-//     lattice boxes / close flags: union / OR over the slabs' components (halo voxels are members of the merged component).
-// k_slab_merge (one workgroup per frame) joins the components and writes the frame's cluster table and, per slab component,
-// its final label; k_slab_gather (one workgroup per slab) moves the voxel records to their ranks in the frame's slot.
-constexpr int SM_THREADS = 1024;
-constexpr int SM_COMP = FR_SLABS_MAX * LB_ST_ROWS;  // component ids: slab * LB_ST_ROWS + table row
-constexpr uint32_t SM_CAND = 0x80000000u;           // flag beside a component's final label
-
-__global__ __launch_bounds__(SM_THREADS) void k_slab_merge(const GridParams g, FrameHdr* hdrs, VoxelArrays va_all, ClusterRec* __restrict__ table_all, FrameScratch fs, uint32_t n_src, uint32_t n_slabs,
-                                                          const UpdateParams up)
-{
-  __shared__ uint32_t s_A[FR_SLABS_MAX][FR_PLANES + 1];  // first voxel of plane z in slab s ([n_planes] = V of the slab)
-  __shared__ uint32_t s_B[FR_SLABS_MAX][FR_PLANES];      // first halo voxel of plane z
-  __shared__ uint32_t s_off[FR_SLABS_MAX][FR_PLANES];    // rank (in the frame) of the slab's first own voxel of plane z
-  __shared__ uint32_t s_hp[FR_PLANES + 1];               // halo voxels of the current slab in the planes before z
-  __shared__ uint32_t s_tot[FR_PLANES];
-  __shared__ uint16_t s_par[SM_COMP];
-  __shared__ uint32_t s_size[SM_COMP], s_cmin[SM_COMP];
-  __shared__ int s_box[SM_COMP][6];
-  __shared__ uint8_t s_close[SM_COMP];
-  __shared__ uint32_t s_V[FR_SLABS_MAX], s_C[FR_SLABS_MAX];
-  __shared__ int s_y1[FR_SLABS_MAX];
-  __shared__ uint32_t s_total, s_bad, s_nc;
-  const uint32_t F = blockIdx.x;
-  const int tid = threadIdx.x;
-  FrameHdr& h = hdrs[F];
-  const uint32_t slot0 = n_src + F * n_slabs;
-  if (tid == 0)
-  {
-    s_bad = 0;
-    s_nc = 0;
-  }
-  if (tid < static_cast<int>(n_slabs))
-  {
-    const FrameHdr& hs = hdrs[slot0 + tid];
-    s_V[tid] = hs.status == VOFOD_OK ? hs.V : 0u;
-    s_C[tid] = hs.status == VOFOD_OK ? hs.C : 0u;
-    s_y1[tid] = hs.slab_y1;
-  }
-  __syncthreads();
-  if (tid < static_cast<int>(n_slabs) && hdrs[slot0 + tid].status != VOFOD_OK)
-    atomicMax(&s_bad, static_cast<uint32_t>(hdrs[slot0 + tid].status));  // (CCL_RETRY_STATUS is the largest code: it wins)
-  if (tid == 0)
-  {
-    // the frame's lattice: what every slab computed from the frame's bounding box
-    const FrameHdr& h0 = hdrs[slot0];
-    for (int a = 0; a < 3; a++)
-    {
-      h.offset[a] = h0.offset[a];
-      h.min_b[a] = h0.min_b[a];
-      h.div_b[a] = h0.div_b[a];
-    }
-    h.n_cells = h0.n_cells;
-    h.n_words = h0.n_words;
-    h.need_words = h0.need_words;
-    h.n_in = h0.n_in;
-  }
-  __syncthreads();
-  if (s_bad)
-  {
-    if (tid == 0)
-    {
-      h.status = static_cast<int32_t>(s_bad);
-      h.V = h.C = h.n_cand = 0;
-    }
-    return;
-  }
-  const FrameHdr& h0 = hdrs[slot0];
-  if (h0.n_in == 0)
-    return;  // an empty frame: V = C = 0 from k_init_hdr
-  const int dv1 = h0.div_b[1];
-  const uint32_t n_planes = 4u * static_cast<uint32_t>((h0.div_b[2] + 3) >> 2);
-  // ---- plane tables
-  for (uint32_t i = tid; i < n_slabs * (n_planes + 1); i += SM_THREADS)
-  {
-    const uint32_t sl = i / (n_planes + 1), z = i - sl * (n_planes + 1);
-    const uint32_t* pl = fs.planes + static_cast<size_t>(slot0 + sl) * 3 * FR_PLANES;
-    s_A[sl][z] = s_V[sl] == 0u ? 0u : (z == n_planes ? s_V[sl] : pl[z]);
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < n_slabs * n_planes; i += SM_THREADS)
-  {
-    const uint32_t sl = i / n_planes, z = i - sl * n_planes;
-    const uint32_t* pl = fs.planes + static_cast<size_t>(slot0 + sl) * 3 * FR_PLANES;
-    // (a slab whose own rows reach the lattice's end has no halo: its planes end where the next begins)
-    s_B[sl][z] = s_V[sl] == 0u ? 0u : (s_y1[sl] < dv1 ? pl[FR_PLANES + z] : s_A[sl][z + 1]);
-  }
-  __syncthreads();
-  for (uint32_t z = tid; z < n_planes; z += SM_THREADS)
-  {
-    uint32_t t = 0;
-    for (uint32_t sl = 0; sl < n_slabs; sl++)
-      t += s_B[sl][z] - s_A[sl][z];
-    s_tot[z] = t;
-  }
-  __syncthreads();
-  if (tid == 0)
-  {
-    uint32_t run = 0;
-    for (uint32_t z = 0; z < n_planes; z++)
-    {
-      const uint32_t t = s_tot[z];
-      s_tot[z] = run;
-      run += t;
-    }
-    s_total = run;
-  }
-  for (uint32_t i = tid; i < n_slabs * LB_ST_ROWS; i += SM_THREADS)
-  {
-    s_par[i] = static_cast<uint16_t>(i);
-    s_size[i] = 0u;
-    s_cmin[i] = 0xffffffffu;
-    s_close[i] = 0;
-    for (int a = 0; a < 3; a++)
-    {
-      s_box[i][a] = 0x7fffffff;
-      s_box[i][3 + a] = static_cast<int>(0x80000000u);
-    }
-  }
-  __syncthreads();
-  for (uint32_t z = tid; z < n_planes; z += SM_THREADS)
-  {
-    uint32_t run = s_tot[z];
-    for (uint32_t sl = 0; sl < n_slabs; sl++)
-    {
-      s_off[sl][z] = run;
-      run += s_B[sl][z] - s_A[sl][z];
-      fs.planes[static_cast<size_t>(slot0 + sl) * 3 * FR_PLANES + 2 * FR_PLANES + z] = s_off[sl][z];  // for k_slab_gather
-    }
-  }
-  const uint32_t V = s_total;
-  if (V > g.vox_cap)
-  {
-    if (tid == 0)
-    {
-      h.status = VOFOD_ERR_CAPACITY;
-      h.V = 0;
-    }
-    return;
-  }
-  auto find = [&](uint32_t v) {
-    uint32_t p;
-    while ((p = lb_ld16(s_par, v)) != v)
-      v = p;
-    return v;
-  };
-  // ---- the halo voxels of every slab join their component with their twin's
-  for (uint32_t sl = 0; sl + 1 < n_slabs; sl++)
-  {
-    __syncthreads();  // (s_hp of the previous slab is dead; s_off complete)
-    if (s_V[sl] == 0u || s_y1[sl] >= dv1)
-      continue;
-    if (tid == 0)
-    {
-      uint32_t run = 0;
-      for (uint32_t z = 0; z < n_planes; z++)
-      {
-        s_hp[z] = run;
-        run += s_A[sl][z + 1] - s_B[sl][z];
-      }
-      s_hp[n_planes] = run;
-    }
-    __syncthreads();
-    const uint32_t H = s_hp[n_planes];
-    const uint16_t* comp = reinterpret_cast<const uint16_t*>(frame_voxels(va_all, slot0 + sl, g.vox_cap).bb);
-    const uint16_t* comp_next = reinterpret_cast<const uint16_t*>(frame_voxels(va_all, slot0 + sl + 1, g.vox_cap).bb);
-    constexpr int HB = 4;  // halo voxels per thread and round: their component indices are fetched together
-    for (uint32_t k0 = tid; k0 < H; k0 += SM_THREADS * HB)
-    {
-      uint32_t ca[HB], cb[HB];
-      bool ok[HB];
-#pragma unroll
-      for (int u = 0; u < HB; u++)
-      {
-        const uint32_t k = k0 + u * SM_THREADS;
-        ok[u] = k < H;
-        ca[u] = cb[u] = 0;
-        if (!ok[u])
-          continue;
-        uint32_t lo = 0, hi = n_planes;  // plane with hp[lo] <= k < hp[hi]
-        while (hi - lo > 1)
-        {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_hp[mid] <= k)
-            lo = mid;
-          else
-            hi = mid;
-        }
-        const uint32_t i = s_B[sl][lo] + (k - s_hp[lo]);
-        const uint32_t twin = s_A[sl + 1][lo] + (k - s_hp[lo]);
-        if (twin >= s_B[sl + 1][lo])
-        {
-          atomicOr(&s_bad, 1u);  // cannot happen (a slab is at least a halo thick): the batch takes the general path
-          ok[u] = false;
-          continue;
-        }
-        ca[u] = comp[i];
-        cb[u] = comp_next[twin];
-      }
-#pragma unroll
-      for (int u = 0; u < HB; u++)
-      {
-        if (!ok[u])
-          continue;
-        uint32_t ra = find(sl * LB_ST_ROWS + ca[u]), rb = find((sl + 1) * LB_ST_ROWS + cb[u]);
-        while (ra != rb)
-        {
-          if (ra < rb)
-          {
-            const uint32_t t = ra;
-            ra = rb;
-            rb = t;
-          }
-          const uint32_t old = lb_cas16(s_par, ra, ra, rb);
-          if (old == ra)
-            break;
-          ra = old;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (s_bad)
-  {
-    if (tid == 0)
-    {
-      h.status = CCL_RETRY_STATUS;
-      h.V = 0;
-    }
-    return;
-  }
-  // ---- flatten; the merged components' sizes, boxes, close flags, labels out of the slabs' cluster tables
-  {
-    constexpr int RPT = (SM_COMP + SM_THREADS - 1) / SM_THREADS;
-    uint32_t roots[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; r++)
-    {
-      const uint32_t i = r * SM_THREADS + tid;
-      roots[r] = i < n_slabs * LB_ST_ROWS ? find(i) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RPT; r++)
-    {
-      const uint32_t i = r * SM_THREADS + tid;
-      if (i < n_slabs * LB_ST_ROWS)
-        s_par[i] = static_cast<uint16_t>(roots[r]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RPT; r++)
-    {
-      const uint32_t i = r * SM_THREADS + tid;
-      if (i >= n_slabs * LB_ST_ROWS)
-        continue;
-      const uint32_t sl = i / LB_ST_ROWS, c = i - sl * LB_ST_ROWS;
-      if (c >= s_C[sl])
-        continue;
-      const ClusterRec rec = table_all[static_cast<size_t>(slot0 + sl) * g.vox_cap + c];
-      const uint32_t root = roots[r];
-      if (rec.close)
-        s_close[root] = 1;
-      for (int a = 0; a < 3; a++)
-      {
-        atomicMin(&s_box[root][a], rec.imin[a]);
-        atomicMax(&s_box[root][3 + a], rec.imax[a]);
-      }
-      if (rec.size)
-        atomicAdd(&s_size[root], rec.size);
-      if (rec.root != 0xffffffffu)
-      {
-        // the component's first own voxel (slab rank rec.root) -> its rank in the frame
-        uint32_t lo = 0, hi = n_planes;
-        while (hi - lo > 1)
-        {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_A[sl][mid] <= rec.root)
-            lo = mid;
-          else
-            hi = mid;
-        }
-        atomicMin(&s_cmin[root], s_off[sl][lo] + (rec.root - s_A[sl][lo]));
-      }
-    }
-    __syncthreads();
-  }
-  // ---- cluster table of the frame, candidate decision (as k_frame_lds); every slab component learns its final label
-  ClusterRec* table = table_all + static_cast<size_t>(F) * g.vox_cap;
-  for (uint32_t i = tid; i < n_slabs * LB_ST_ROWS; i += SM_THREADS)
-  {
-    const uint32_t sl = i / LB_ST_ROWS, c = i - sl * LB_ST_ROWS;
-    if (c >= s_C[sl] || s_par[i] != i)
-      continue;
-    ClusterRec rec;
-    rec.root = s_cmin[i];
-    rec.size = s_size[i];
-    int ext_ok = 1;
-    for (int a = 0; a < 3; a++)
-    {
-      rec.imin[a] = s_box[i][a];
-      rec.imax[a] = s_box[i][3 + a];
-      ext_ok &= (static_cast<float>(rec.imax[a] - rec.imin[a]) * g.leaf[a] <= up.cand_max_extent);
-    }
-    rec.close = s_close[i];
-    const bool cand = !rec.close && static_cast<int>(rec.size) >= up.min_points && ext_ok;
-    rec.cand = cand ? 1u : 0u;
-    if (cand)
-      s_cmin[i] |= SM_CAND;  // (labels are ranks: far below 2^31)
-    table[atomicAdd(&s_nc, 1u)] = rec;
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < n_slabs * LB_ST_ROWS; i += SM_THREADS)
-  {
-    const uint32_t sl = i / LB_ST_ROWS, c = i - sl * LB_ST_ROWS;
-    if (c < s_C[sl])
-      fs.bmin[static_cast<size_t>(slot0 + sl) * LB_MAX + c] = s_cmin[s_par[i]];  // (the slot's brick minima are dead)
-  }
-  if (tid == 0)
-  {
-    h.V = V;
-    h.C = s_nc;
-    uint32_t nb = 0;
-    for (uint32_t sl = 0; sl < n_slabs; sl++)
-      nb += hdrs[slot0 + sl].n_bricks;
-    h.n_bricks = nb;
-  }
-}
-
-// one workgroup per slab: its own voxels' records, labels and candidate members at their ranks in the frame's slot
-constexpr int SG_THREADS = 512;
-__global__ __launch_bounds__(SG_THREADS) void k_slab_gather(const GridParams g, FrameHdr* hdrs, VoxelArrays va_all, uint32_t* __restrict__ labels_all, CandMember* __restrict__ cand_all, FrameScratch fs,
-                                                           uint32_t n_src, uint32_t n_slabs)
-{
-  __shared__ uint32_t s_A[FR_PLANES + 1], s_B[FR_PLANES], s_off[FR_PLANES];
-  __shared__ uint32_t s_lab[LB_ST_ROWS];
-  const uint32_t F = blockIdx.x / n_slabs, sl = blockIdx.x - F * n_slabs;
-  const uint32_t slot = n_src + blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const FrameHdr& hs = hdrs[slot];
-  FrameHdr& h = hdrs[F];
-  if (h.status != VOFOD_OK || h.V == 0u || hs.status != VOFOD_OK || hs.V == 0u)
-    return;
-  const uint32_t Vs = hs.V, Cs = hs.C;
-  const int dv1 = hs.div_b[1];
-  const uint32_t n_planes = 4u * static_cast<uint32_t>((hs.div_b[2] + 3) >> 2);
-  const uint32_t* pl = fs.planes + static_cast<size_t>(slot) * 3 * FR_PLANES;
-  for (uint32_t z = tid; z <= n_planes; z += SG_THREADS)
-    s_A[z] = z == n_planes ? Vs : pl[z];
-  __syncthreads();
-  for (uint32_t z = tid; z < n_planes; z += SG_THREADS)
-  {
-    s_B[z] = hs.slab_y1 < dv1 ? pl[FR_PLANES + z] : s_A[z + 1];
-    s_off[z] = pl[2 * FR_PLANES + z];
-  }
-  for (uint32_t c = tid; c < Cs; c += SG_THREADS)
-    s_lab[c] = fs.bmin[static_cast<size_t>(slot) * LB_MAX + c];
-  __syncthreads();
-  const VoxelArrays vs = frame_voxels(va_all, slot, g.vox_cap), vf = frame_voxels(va_all, F, g.vox_cap);
-  const uint16_t* comp = reinterpret_cast<const uint16_t*>(vs.bb);
-  uint32_t* labels = labels_all + static_cast<size_t>(F) * g.vox_cap;
-  CandMember* cands = cand_all + static_cast<size_t>(F) * g.vox_cap;
-  constexpr int GU = 4;
-  const uint32_t Vr = (Vs + 63u) & ~63u;
-  for (uint32_t i0 = tid; i0 < Vr; i0 += SG_THREADS * GU)
-  {
-    float4 pt[GU];
-    uint32_t cm[GU];
-#pragma unroll
-    for (int u = 0; u < GU; u++)
-    {
-      const uint32_t i = i0 + u * SG_THREADS;
-      cm[u] = 0;
-      pt[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (i < Vs)
-      {
-        pt[u] = vs.pts[i];
-        cm[u] = comp[i];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < GU; u++)
-    {
-      const uint32_t i = i0 + u * SG_THREADS;
-      if (i0 + u * SG_THREADS - tid >= Vr)  // block-uniform
-        break;
-      bool cand = false;
-      uint32_t G = 0, label = 0;
-      if (i < Vs)
-      {
-        uint32_t lo = 0, hi = n_planes;
-        while (hi - lo > 1)
-        {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_A[mid] <= i)
-            lo = mid;
-          else
-            hi = mid;
-        }
-        if (i < s_B[lo])
-        {
-          G = s_off[lo] + (i - s_A[lo]);
-          const uint32_t lc = s_lab[cm[u]];
-          label = lc & ~SM_CAND;
-          cand = (lc & SM_CAND) != 0u;
-          vf.pts[G] = pt[u];
-          labels[G] = label;
-        }
-      }
-      const unsigned long long m = __ballot(cand);
-      if (m)
-      {
-        const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        uint32_t base = 0;
-        if (lane == leader)
-          base = atomicAdd(&h.n_cand, static_cast<uint32_t>(__popcll(m)));
-        base = __builtin_amdgcn_readlane(base, leader);
-        if (cand)
-        {
-          CandMember c2;
-          c2.root = label;
-          c2.v = G;
-          cands[base + __popcll(m & ((1ull << lane) - 1ull))] = c2;
-        }
-      }
-    }
-  }
-}
+constexpr auto k_frame_lds_full = &k_frame_lds<0>;  // voxelise + cluster everything (debug view, cold maps)
+constexpr auto k_frame_lds_far = &k_frame_lds<1>;   // voxelise + cluster the far voxels only (read-only batches)
 
 }  // namespace vk

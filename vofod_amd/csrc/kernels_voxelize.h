@@ -76,27 +76,15 @@ __device__ __forceinline__ int wave_max(int v)
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
 
-// Frame/block decode of the 1-D launches that cover n_frames frames with gx blocks each.  With xcd_map the
-// hardware's round-robin block->XCD dealing (block b runs on XCD b % 8: observed, used for speed only) is
-// turned into "every block of frame f runs on XCD f % 8", so a frame's bitmap, prefix array, voxel records and
-// brick words (a few MB) stay resident in that XCD's 4 MB L2 across the whole kernel chain.
+// Frame/block decode of the 1-D launches that cover n_frames frames with gx blocks each.  (Round 1 also had an XCD-aware
+// dealing - every block of frame f on XCD f % 8 - behind a switch: measured 5-9 % slower than the hardware's round robin, removed.)
 __device__ __forceinline__ bool frame_block(const GridParams& g, uint32_t& frame, uint32_t& bx, uint32_t& gx)
 {
   const uint32_t L = blockIdx.x;
-  if (!g.xcd_map)
-  {
-    gx = gridDim.x / g.n_frames;
-    frame = L / gx;
-    bx = L - frame * gx;
-    return true;
-  }
-  const uint32_t fpx = (g.n_frames + 7u) >> 3;
-  gx = gridDim.x / (8u * fpx);
-  const uint32_t xcd = L & 7u, idx = L >> 3;
-  const uint32_t local = idx / gx;
-  bx = idx - local * gx;
-  frame = local * 8u + xcd;
-  return frame < g.n_frames;
+  gx = gridDim.x / g.n_frames;
+  frame = L / gx;
+  bx = L - frame * gx;
+  return true;
 }
 
 __device__ __forceinline__ float ldf(const char* base, uint64_t stride, uint32_t i) { return *reinterpret_cast<const float*>(base + static_cast<uint64_t>(i) * stride); }

@@ -344,7 +344,7 @@ struct Workspace
 
   void release()
   {
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave, fs.planes, fs.cuts};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -431,8 +431,6 @@ struct Workspace
     WS_ALLOC(fs.bmin, sizeof(uint32_t) * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.nodeA, sizeof(unsigned long long) * 4 * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.bbsave, sizeof(unsigned long long) * FR_BB64 * static_cast<size_t>(F));
-    WS_ALLOC(fs.planes, sizeof(uint32_t) * 3 * FR_PLANES * static_cast<size_t>(F));
-    WS_ALLOC(fs.cuts, sizeof(int32_t) * (FR_SLABS_MAX + 2) * static_cast<size_t>(F));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -855,7 +853,6 @@ void fill_grid_params(vofod_handle* h, GridParams& g, const float leaf[3], bool 
   g.words_cap = ws.words_cap;
   g.vox_cap = ws.vox_cap;
   g.n_frames = 1;
-  g.xcd_map = 0;
   g.sparse_prefix = 0;
 }
 
@@ -982,12 +979,7 @@ int stage_cloud(vofod_handle* h, Workspace& ws, uint32_t f, const void* x, const
 }
 
 // 1-D grid of a per-frame kernel: n_frames x gx blocks (see frame_block in kernels_voxelize.h)
-inline dim3 fgrid(const GridParams& g, uint32_t gx)
-{
-  if (!g.xcd_map)
-    return dim3(g.n_frames * gx);
-  return dim3(8u * ((g.n_frames + 7u) / 8u) * gx);
-}
+inline dim3 fgrid(const GridParams& g, uint32_t gx) { return dim3(g.n_frames * gx); }
 
 // Reference lattice of the single-pass input (kernels_frame.h, k_key1): what voxel_grid_weighted.cpp:72-106 yields for a cloud
 // whose minimum is the operation area's corner, and the band around cell boundaries inside which the frame's own offset may
@@ -1028,11 +1020,8 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   bpv.bricks_cap = ws.bricks_cap;
   ws.bricks_preset = bricks != nullptr;
   g.n_frames = n;
-  // measured on MI355X (32 frames, 0.25 m): the XCD-aware mapping is 5-9 % slower than plain dealing, so it is opt-in
-  static const bool xcd_on = std::getenv("VOFOD_XCD_MAP") && std::atoi(std::getenv("VOFOD_XCD_MAP")) == 1;
-  g.xcd_map = (n >= 8 && xcd_on) ? 1u : 0u;
   // lean emission: the LDS clustering kernel will follow and initialises the per-root slots itself (see plan_lds_ccl)
-  ws.lean_emit = lean_hint && !bricks && !g.xcd_map && !two_phase;
+  ws.lean_emit = lean_hint && !bricks && !two_phase;
   ws.slab_bitmap = false;
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
@@ -1056,7 +1045,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     // one pass over the input: bounding box + reference cells (k_key1), then the frames' lattices
     // (k_init_hdr has cleared the frames' list counters; one workgroup per KEY1_THREADS * KEY1_PPT points, no stride loop)
     const uint32_t gk1 = std::max(1u, (max_pts + KEY1_THREADS * KEY1_PPT - 1) / (KEY1_THREADS * KEY1_PPT));
-    const dim3 gk = g.xcd_map ? fgrid(g, gk1) : dim3(gk1, n);  // (blockIdx.y = frame: see k_key1)
+    const dim3 gk(gk1, n);  // (blockIdx.y = frame: see k_key1)
     if (packed)
       KLAUNCH(h, k_key1<true>, gk, dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
     else
@@ -1096,7 +1085,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   static const bool slabs_on = !(std::getenv("VOFOD_SLABS") && std::atoi(std::getenv("VOFOD_SLABS")) == 0);
   constexpr uint32_t SLAB_MAX = 32;
   const uint32_t n_slabs = (ws.words_cap + SLAB_WORDS64 - 1) / SLAB_WORDS64;
-  if (slabs_on && n >= 4 && !want_ptrank && !bricks && n_slabs <= SLAB_MAX && !g.xcd_map)  // a single frame is served faster by the whole chip through the global bitmap
+  if (slabs_on && n >= 4 && !want_ptrank && !bricks && n_slabs <= SLAB_MAX)  // a single frame is served faster by the whole chip through the global bitmap
   {
     ws.slab_bitmap = true;
     if (!ws.bitmap_clean && !g.sparse_prefix)  // voxel-level clustering: neighbour windows run into the words past the lattice, they must read as zero
@@ -1375,40 +1364,13 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           HIPCHK(hipMemset(d_prof + 32 * static_cast<size_t>(s0), 0, sizeof(unsigned long long) * 32 * cnt));
                   return VOFOD_OK;
         };
-        // Batches that leave most CUs idle under one workgroup per frame: each frame is split into y-slabs, one workgroup per
-        // slab (k_frame_lds<true>), the slabs' results joined by k_slab_merge.  Slab s of frame f uses slot n + f * S + s of the
-        // workspace, so the split is as deep as the free slots allow (32 frames in a 256-frame workspace: 7 slabs).
-        // Opt-in (VOFOD_SLABS_PER_FRAME=N, N >= 2: up to N slabs): measured on 32-frame batches the frame stage shrinks from
-        // 320 to 195 us (+ 60 us of cuts / merge / gather), but the rate of pipelined small batches is set by the latency of the
-        // cross-stream hand-offs, not by the kernels: 125 k frames/s with slabs, 131 k without.  One workgroup per frame stays
-        // the default; the slab path is kept (and tested) for callers that need the latency of a single small batch.
-        const int slabs_env = std::getenv("VOFOD_SLABS_PER_FRAME") ? std::atoi(std::getenv("VOFOD_SLABS_PER_FRAME")) : 1;
-        uint32_t n_slabs = 1;
-        if (n < 128u && up_tables && mapclose && ws.ref_lattice.on && ws.F >= 3u * n)
-          n_slabs = std::min<uint32_t>({static_cast<uint32_t>(std::max(slabs_env, 1)), static_cast<uint32_t>(FR_SLABS_MAX), ws.F / n - 1u});
-        if (n_slabs >= 2)
-        {
-          KLAUNCH(h, k_slab_cuts, dim3(n), dim3(1024), g, bp, ws.d_hdrs, ws.sa, ws.pt_cap, ws.fs, ws.ref_lattice, n_slabs);
-          KLAUNCH(h, k_frame_lds_full<true>, dim3(n * n_slabs), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
-                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, n_slabs, 0);
-          KLAUNCH(h, k_slab_merge, dim3(n), dim3(SM_THREADS), g, ws.d_hdrs, ws.va, ws.d_table, ws.fs, n, n_slabs, *up_tables);
-          KLAUNCH(h, k_slab_gather, dim3(n * n_slabs), dim3(SG_THREADS), g, ws.d_hdrs, ws.va, ws.d_labels, ws.d_cand, ws.fs, n, n_slabs);
-          if (d_prof)
-            if (const int pr = print_prof(n, n * n_slabs); pr != VOFOD_OK)
-              return pr;
-          ws.finalize_fused = true;
-          ws.closefar_fused = true;
-          HIPCHK(hipGetLastError());
-          return VOFOD_OK;
-        }
         ws.far_ran = up_tables && mapclose && ws.close_first;
         if (ws.far_ran)  // read-only batches: cluster the far voxels only (the close-first instantiation)
           KLAUNCH(h, k_frame_lds_far, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
-                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, n, 1u, ws.close_first);
+                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, ws.close_first);
         else
-          KLAUNCH(h, k_frame_lds_full<false>, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
-                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, n,
-                  1u, 0);
+          KLAUNCH(h, k_frame_lds_full, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
+                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, 0);
         ws.finalize_fused = up_tables && mapclose;
         if (d_prof)
           if (const int pr = print_prof(0, n); pr != VOFOD_OK)
@@ -1424,16 +1386,15 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     if (!ws.bricks_preset)
       KLAUNCH(h, k_brick_set, fgrid(g, gv), dim3(256), g, bp, ws.d_hdrs, ws.va, ws.ba);
     ws.bricks_preset = false;
-    static const int bmode = std::getenv("VOFOD_BRICK_MODE") ? std::atoi(std::getenv("VOFOD_BRICK_MODE")) : 3;  // 1 fused probe+union, 2 masks + batched hooking (slower), 3 masks + transitive reduction
-    if ((bmode == 2 || bmode == 3) && bp.n_off <= 64 && ct->d_pair)
+    // the stencil's pairs as per-brick connectivity masks + transitive reduction; a stencil beyond 64 offsets (or without the
+    // pair tables) takes the fused probe + union kernel.  (Round 1 also had "masks + batched hooking" behind VOFOD_BRICK_MODE=2:
+    // CAS storms, 470 us against 206 us - removed in round 4.)
+    if (bp.n_off <= 64 && ct->d_pair)
     {
       // ws.d_table is free until k_finalize: it holds the per-brick connectivity masks (list order) in between
       unsigned long long* conn = reinterpret_cast<unsigned long long*>(ws.d_table);
-      KLAUNCH(h, k_brick_conn, fgrid(g, gv * CONN_LANES), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba, conn, bmode == 3 ? ws.d_bconn : nullptr);
-      if (bmode == 3)
-        KLAUNCH(h, k_brick_link_tr, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_pair, ws.d_hdrs, ws.ba, conn, ws.d_bconn);
-      else
-        KLAUNCH(h, k_brick_link, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ws.d_hdrs, ws.ba, conn);
+      KLAUNCH(h, k_brick_conn, fgrid(g, gv * CONN_LANES), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba, conn, ws.d_bconn);
+      KLAUNCH(h, k_brick_link_tr, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_pair, ws.d_hdrs, ws.ba, conn, ws.d_bconn);
     }
     else
       KLAUNCH(h, k_brick_union<1>, fgrid(g, gv), dim3(256), g, bp, ct->d_boffs, ct->d_sure, ct->d_amb, ws.d_hdrs, ws.ba);
@@ -1737,27 +1698,25 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   };
   // In-flight batches on streams of their own overlap their kernel chains: a gain while a batch leaves CUs idle (32 / 64 /
   // 128 frames: +31 / +56 / +16 %), a loss once one batch's kernels fill the chip (256 frames: -6 %, co-running chains only
-  // slow each other down).  VOFOD_TWO_CHAINS=0 / 1 forces one or the other.
+  // slow each other down).
   // Round 2: the chains are staggered.  A batch's streaming kernels (bounding box, brick codes: HBM bound, a few waves per CU)
   // start when the previous batch's have finished, i.e. while that batch's frame kernel (LDS bound, one workgroup per CU)
-  // runs: the two phases of consecutive batches share the chip instead of taking turns (VOFOD_STAGGER=0: free-running chains).
-  static const int two_chains_env = std::getenv("VOFOD_TWO_CHAINS") ? std::atoi(std::getenv("VOFOD_TWO_CHAINS")) : -1;
-  static const bool stagger_on = !(std::getenv("VOFOD_STAGGER") && std::atoi(std::getenv("VOFOD_STAGGER")) == 0);
-  const bool two_chains = two_chains_env >= 0 ? two_chains_env != 0 : true;
+  // runs: the two phases of consecutive batches share the chip instead of taking turns.
+  // (Rounds 2-3 kept VOFOD_TWO_CHAINS / VOFOD_STAGGER / VOFOD_PIPE / VOFOD_FRAME_STREAMS to switch these schemes off: lost
+  // experiments, removed in round 4 with their code paths - DESIGN 5.3 has the measurements.)
+  constexpr bool two_chains = true, stagger_on = true;
   // Submitted batches run as a three-stage pipeline on three streams: the streaming kernels (bounding box + brick codes:
   // vector-instruction bound, a few waves per CU) of every batch on a low-priority stream, the frame kernels (one 156 KB
   // workgroup per CU, latency bound) on a second one, the classification tails on a third (high priority).  The streaming
   // kernels of batch k+1 then fill the issue slots the frame kernel of batch k leaves idle, and when both are ready at the
   // same moment the frame kernel's workgroups are placed first (a CU full of streaming waves has no room for one).
-  // VOFOD_PIPE=ticket: a stream per ticket (round 2's first scheme: chains of queued batches start as they are submitted).
-  static const bool per_ticket_streams = std::getenv("VOFOD_PIPE") && std::string(std::getenv("VOFOD_PIPE")) == "ticket";
   hipStream_t my_stream = nullptr;
   bool staged = false;
   if (two_chains && phase == FRAMES_LAUNCH)
   {
     // (a batch that leaves most CUs idle - fewer frames than half the CUs - gains more from whole chains running side by
     // side: its frame kernel shares the chip with the frame kernels of the other batches in flight)
-    if (per_ticket_streams || !h->stream_key || !h->stream_frame || n < 128u)
+    if (!h->stream_key || !h->stream_frame || n < 128u)
     {
       for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
         if (&ws == h->slot(t))
@@ -1869,13 +1828,11 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     if (r != VOFOD_OK)
       return r;
     g.sparse_prefix = want_bricks(ct, ws) ? 1u : 0u;
-    BrickParams bp = ct->bp;
-    // Fusing the brick registration into k_emit was measured slower (194 us vs 96 + 50 us for 32 frames: the returning
-    // atomicOr sits inside the load-balanced emission loop), so it stays a kernel of its own unless VOFOD_FUSE_BRICKS=1.
-    static const bool fuse = std::getenv("VOFOD_FUSE_BRICKS") && std::atoi(std::getenv("VOFOD_FUSE_BRICKS")) == 1;
+    // (Fusing the brick registration into k_emit was measured slower - 194 us vs 96 + 50 us for 32 frames: the returning
+    // atomicOr sits inside the load-balanced emission loop - so it stays a kernel of its own.)
     const bool lds_plan = plan_lds_ccl(h, ct, ws, no_update && n >= 4);
     h->lds_ccl_off = false;  // one-shot: only the re-run of the batch that overflowed stays off the LDS kernels
-    r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false, (fuse && want_bricks(ct, ws)) ? &bp : nullptr, lds_plan);
+    r = launch_voxelize(h, ws, g, n, static_cast<uint32_t>(npts), false, false, nullptr, lds_plan);
   }
   if (r != VOFOD_OK)
     return r;
@@ -1888,9 +1845,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     // kernel k (its workgroups take the CUs as those of k retire: frames last 260-350 us) nor for the 14 us launch hand-off
     // behind it.  Measured +2..4 % (541 / 533 / 533 k against 519 / 510 / 534 k frames/s, alternating runs on one box); the
     // pipeline's pace is then set by k_key1, which runs as a guest of the frame kernels all the time (one wave per SIMD beside a
-    // frame workgroup: ~440 us per batch).  VOFOD_FRAME_STREAMS=1: one frame stream.
-    static const bool two_frame_streams = !(std::getenv("VOFOD_FRAME_STREAMS") && std::atoi(std::getenv("VOFOD_FRAME_STREAMS")) == 1);
-    h->stream = (two_frame_streams && h->stream_frame2 && (h->frame_toggle ^= 1)) ? h->stream_frame2 : h->stream_frame;
+    // frame workgroup: ~440 us per batch).
+    h->stream = (h->stream_frame2 && (h->frame_toggle ^= 1)) ? h->stream_frame2 : h->stream_frame;
     HIPCHK(hipStreamWaitEvent(h->stream, ws.ev_key, 0));
   }
 
