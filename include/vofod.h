@@ -280,6 +280,11 @@ int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* t
  * VOFOD_ERR_CAPACITY with *n_out = the detections to make room for; the ticket then stays pending and no ids are handed out
  * (batches of >= 4 frames; a batch that had to take the host tail is consumed by the failing call). */
 int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket);
+/* Allocates now what the first `tickets` (1..8) batches in flight would otherwise allocate inside their first
+ * vofod_batch_submit (workspaces of max_batch_frames slots, flood-fill buffers of the device tail: hundreds of ms of
+ * allocation in a real-time caller's first calls).  Optional; the reference has no counterpart (its buffers are
+ * std::vectors grown on use). */
+int vofod_reserve(vofod_handle* h, int tickets);
 int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out);
 
 /* raycast_cloud :1397-1605 split where the reference thread blocks on m_detection_cv (:1530-1537):

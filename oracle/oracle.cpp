@@ -920,6 +920,11 @@ int ORACLE_API(process_batch)(vofod_handle* h, const vofod_scan* scans, const fl
   return ret;
 }
 
+int ORACLE_API(reserve)(vofod_handle* h, int tickets)
+{
+  return (h && tickets >= 1 && tickets <= 8) ? VOFOD_OK : VOFOD_ERR_INVALID_ARG;  // nothing to allocate on the CPU
+}
+
 int ORACLE_API(batch_submit)(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, int* ticket)
 {
   if (!h || !scans || !tfs || !ticket)

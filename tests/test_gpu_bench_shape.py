@@ -46,9 +46,34 @@ def _compare_batches(ref, dev, scans, tfs, chunk=32, clusters_cap=8192):
     return gb, n_det, db
 
 
-def test_bench_workload_256_frames_os1_128(oracle, hip):
+def _compare_far_views(ref, dev, scans, tfs, chunk=32, clusters_cap=8192):
+    """the far-only debug view of the HIP path (the close-first kernel's own output) against the far part of the oracle's full
+    clustering, frame by frame"""
+    from helpers import far_view
+
+    n = len(scans)
+    db, pb, gb = dev.process_batch(scans, tfs, debug=True, clusters_cap=clusters_cap, far_only=True)
+    for f0 in range(0, n, chunk):
+        f1 = min(f0 + chunk, n)
+        da, pa, ga = ref.process_batch(scans[f0:f1], tfs[f0:f1], debug=True, clusters_cap=clusters_cap)
+        np.testing.assert_array_equal(pb[f0:f1], pa)
+        for k, (x, y) in enumerate(zip(ga, gb[f0:f1])):
+            try:
+                assert_scan_debug_equal(far_view(x), y)
+            except AssertionError as e:
+                raise AssertionError(f"far view, frame {f0 + k}: {e}") from e
+
+
+@pytest.mark.parametrize("fallback", ["", "VOFOD_CLOSE_FIRST=0", "VOFOD_DEVICE_TAIL=0", "VOFOD_ONEPASS=0", "VOFOD_LDS_MAX_BRICKS=4096"])
+def test_bench_workload_256_frames_os1_128(oracle, hip, fallback, monkeypatch):
     """configs[3] on one GPU = the bench.py default: 256 x OS1-128 @ 0.25 m, the warmed map, vofod_batch_submit/collect
-    (k_key1 -> k_frame_lds -> device tail), every frame against the oracle"""
+    (k_key1 -> k_frame_lds_far -> k_tail_far), every frame against the oracle - by default and under each production fallback:
+    the full clustering (what a cold map takes), the host tail (what a capacity of the device tail falls back to), the two-pass
+    input, and frames beyond the LDS image (every frame here holds more than 4096 bricks: the batch is run again on the
+    global-memory kernels).  The switches are read on every call (vofod_hip.hip switch_off)."""
+    if fallback:
+        k, v = fallback.split("=")
+        monkeypatch.setenv(k, v)
     F = 256
     ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=F)
     scene = synth.bench_scene()
@@ -59,8 +84,19 @@ def test_bench_workload_256_frames_os1_128(oracle, hip):
     tfs = np.stack([s.tf for s in frames])
     gb, n_det, db_full = _compare_batches(ref, dev, scans, tfs)
     assert min(len(g["weighted"]) for g in gb) > 15_000 and max(g["n_input_after_crop"] for g in gb) > 49_152
+    if not fallback:
+        _compare_far_views(ref, dev, scans, tfs)
     # the pipelined form bench.py uses: two tickets in flight give the same detections as the synchronous call
+    dev.reserve(2)  # (workspaces of both tickets allocated here, not inside the submits)
+    dev.lib.profile_enable(dev.h, 1)
     want = dev.process_batch(scans, tfs)
+    names = _profiled_kernels(dev.lib, dev)
+    dev.lib.profile_enable(dev.h, 0)
+    if not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK"):
+        expect = {"": "k_frame_lds_far", "VOFOD_CLOSE_FIRST=0": "k_frame_lds_full", "VOFOD_DEVICE_TAIL=0": "k_pack_lite", "VOFOD_ONEPASS=0": "k_key2<true>", "VOFOD_LDS_MAX_BRICKS=4096": "k_brick_root"}[fallback]
+        assert expect in names, (fallback, names)
+        if fallback in ("", "VOFOD_ONEPASS=0"):
+            assert "k_tail_far" in names, names
     # (the calls without debug output read back the lite slots - candidate clusters only; the debug call above the full tables)
     np.testing.assert_array_equal(want[0]["n_points"], db_full["n_points"])
     np.testing.assert_array_equal(want[0]["frame"], db_full["frame"])

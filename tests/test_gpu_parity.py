@@ -644,6 +644,47 @@ def test_host_batch_in_one_block_and_params_changed_in_flight(oracle, hip):
     assert len(g2) == 0 and not per2.any()
 
 
+def test_pinned_host_input_may_be_overwritten_after_submit(oracle, hip):
+    """include/vofod.h: the scans' host buffers need not outlive vofod_batch_submit.  From page-locked memory the H2D copy is
+    truly asynchronous and queued behind the previous batch's streaming kernels: submit returns behind the copy.
+    A caller that refills its arena right after submit - here: zeroes it - must still get the detections of what it submitted."""
+    try:
+        hiprt = C.CDLL("libamdhip64.so")
+    except OSError:
+        pytest.skip("no HIP runtime to page-lock memory with")
+    F = 24
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.25, max_batch=F)
+    synth.warm_map(dev, synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=0), "os1-128", 16)
+    if dev.status().background_pts_sufficient and dev.status().sure_background_sufficient:
+        ref.load_apriori(np.zeros((0, 3), dtype=np.float32))  # both latches, no voxel touched
+    sync_maps(dev, ref)
+    frames = synth.bench_frames(synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=12), "os1-128", F)  # targets that appeared after the warm-up
+    tfs = np.stack([s.tf for s in frames])
+    want, want_per = ref.process_batch([s.scan for s in frames], tfs)
+    assert len(want) >= 1
+    h_, w_, _, _ = synth.SENSORS["os1-128"]
+    n = h_ * w_
+    base = C.c_void_p()
+    hiprt.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    assert hiprt.hipHostMalloc(C.byref(base), F * 3 * n * 4, 0) == 0  # page-locked: one block, x | y | z per frame (the one-copy path)
+    view = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_float)), shape=(F, 3, n))
+    for rnd in range(3):
+        for f, s in enumerate(frames):
+            view[f, 0], view[f, 1], view[f, 2] = s.x, s.y, s.z
+        scans = [ScanData(x=base.value + (3 * f) * n * 4, y=base.value + (3 * f + 1) * n * 4, z=base.value + (3 * f + 2) * n * 4, width=w_, height=h_, stride_bytes=4, memspace=capi.MEM_HOST)
+                 for f in range(F)]
+        t0 = dev.batch_submit(scans, tfs)
+        view[:] = 0.0  # the caller reuses its arena at once
+        t1 = dev.batch_submit(scans, tfs)  # (a batch of no-return pixels: no detections)
+        got, per = dev.batch_collect(t0)
+        got1, per1 = dev.batch_collect(t1)
+        np.testing.assert_array_equal(per, want_per)
+        assert_detections_equal(want, _rebase_ids(got, want))
+        assert len(got1) == 0 and int(per1.sum()) == 0
+    hiprt.hipHostFree.argtypes = [C.c_void_p]
+    hiprt.hipHostFree(base)
+
+
 def test_collect_with_too_small_an_array_keeps_the_ticket(oracle, hip):
     """vofod_batch_collect with an `out` too small: VOFOD_ERR_CAPACITY, *n_out = the size needed, the ticket stays pending and
     the second call returns what the synchronous call returns (ids included: none were handed out by the failing call)"""

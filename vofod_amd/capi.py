@@ -249,6 +249,7 @@ _SIGS = {
     "process_scan": (C.c_int, [C.c_void_p, _P(Scan), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, _P(C.c_size_t), _P(ScanDebug)]),
     "process_batch": (C.c_int, [C.c_void_p, _P(Scan), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, _P(C.c_size_t), _P(ScanDebug)]),
     "batch_submit": (C.c_int, [C.c_void_p, _P(Scan), C.c_void_p, C.c_size_t, _P(C.c_int)]),
+    "reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "batch_collect": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, _P(C.c_size_t)]),
     "raycast_begin": (C.c_int, [C.c_void_p, _P(Scan), C.c_void_p]),
     "raycast_finish": (C.c_int, [C.c_void_p]),

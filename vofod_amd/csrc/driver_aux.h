@@ -1112,6 +1112,35 @@ int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tf
   return r;
 }
 
+int vofod_reserve(vofod_handle* h, int tickets)
+{
+  if (!h || tickets < 1 || tickets > vofod_handle::MAX_INFLIGHT)
+    return VOFOD_ERR_INVALID_ARG;
+  std::scoped_lock lck(h->mtx);
+  (void)hipSetDevice(h->device);
+  for (int t = 0; t < tickets; t++)
+  {
+    Workspace* w = h->slot(t);
+    if (w->F == 0)
+      if (hipError_t e = w->ensure(h->ws.F, h->ws.pt_cap, h->ws.vox_cap, h->ws.words_cap, h->ws.bricks_cap); e != hipSuccess)
+      {
+        h->err = std::string("extra workspace: ") + hipGetErrorString(e);
+        return VOFOD_ERR_DEVICE;
+      }
+    if (t > 0 && !h->chain_stream[t])
+      HIPCHK(hipStreamCreateWithFlags(&h->chain_stream[t], hipStreamNonBlocking));
+  }
+  // the device tail's flood-fill buffers: shared by the batches of 128 frames and more (their tails take turns on the tail
+  // stream), per ticket for smaller batches (process_frames sizes those by the batch; reserved here for full workspaces)
+  if (const int r = ensure_explore(h, h->explore, h->ws.F, static_cast<size_t>(h->ws.F) * vtd::TP_MAXC, static_cast<size_t>(h->ws.F) * vtd::TP_MAXM); r != VOFOD_OK)
+    return r;
+  if (h->ws.F < 128u)
+    for (int t = 0; t < tickets; t++)
+      if (const int r = ensure_explore(h, h->explore_slot[t], h->ws.F, static_cast<size_t>(h->ws.F) * vtd::TP_MAXC, static_cast<size_t>(h->ws.F) * vtd::TP_MAXM); r != VOFOD_OK)
+        return r;
+  return VOFOD_OK;
+}
+
 int vofod_batch_collect(vofod_handle* h, int ticket, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out)
 {
   if (!h || !n_out || ticket < 0 || ticket >= vofod_handle::MAX_INFLIGHT)

@@ -267,6 +267,15 @@ struct Prof
       hipLaunchKernelGGL(kern, grid, block, lds, (h)->stream, __VA_ARGS__);    \
   } while (0)
 
+// VOFOD_<NAME>=0 switches a fast path off (README "Environment switches").  Read on every call, not cached: a dozen getenv per
+// batch cost ~1 us, and the tests flip the fallbacks inside one process (a `static const` here made every switch stick to
+// its first reading - and every in-process fallback test after the first call vacuous).
+inline bool switch_off(const char* name)
+{
+  const char* v = std::getenv(name);
+  return v && std::atoi(v) == 0;
+}
+
 struct Workspace
 {
   uint32_t F = 0, pt_cap = 0, vox_cap = 0, words_cap = 0, nblk_cap = 0, bricks_cap = 0;
@@ -340,6 +349,7 @@ struct Workspace
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev_packed = nullptr;   // the read-back slots are complete on the chain's stream
   hipEvent_t ev_key = nullptr;      // staged pipeline: the batch's streaming kernels (brick codes) are through
+  hipEvent_t ev_h2d = nullptr;      // the host-resident columns of a submitted batch have crossed the link (vofod_batch_submit returns behind it)
   hipStream_t copy_stream = nullptr;  // device-to-host copy of the slots: the chain's stream goes on with the next batch meanwhile
 
   void release()
@@ -362,6 +372,8 @@ struct Workspace
       (void)hipEventDestroy(ev_packed);
     if (ev_key)
       (void)hipEventDestroy(ev_key);
+    if (ev_h2d)
+      (void)hipEventDestroy(ev_h2d);
     if (copy_stream)
       (void)hipStreamDestroy(copy_stream);
     *this = Workspace();
@@ -446,6 +458,8 @@ struct Workspace
     if ((e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess)
       return e;
     if ((e = hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)) != hipSuccess)
+      return e;
+    if ((e = hipEventCreateWithFlags(&ev_h2d, hipEventDisableTiming)) != hipSuccess)
       return e;
     if ((e = hipEventCreateWithFlags(&ev_key, hipEventDisableTiming)) != hipSuccess)
       return e;
@@ -989,7 +1003,7 @@ inline dim3 fgrid(const GridParams& g, uint32_t gx) { return dim3(g.n_frames * g
 RefLattice fill_ref_lattice(const GridParams& g)
 {
   RefLattice rl{};
-  static const bool on = !(std::getenv("VOFOD_ONEPASS") && std::atoi(std::getenv("VOFOD_ONEPASS")) == 0);
+  const bool on = !switch_off("VOFOD_ONEPASS");
   float cmax = 0.0f, dmax = 0.0f, inv_max = 0.0f;
   for (int a = 0; a < 3; a++)
   {
@@ -1082,7 +1096,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   }
   // Lattices of at most SLAB_MAX slabs of 1 Mi cells: the bitmap is built slab by slab in LDS (kernels_slab.h).
   // VOFOD_SLABS=0 keeps the global-atomic kernels (also used for the counted grid, which needs every point's rank).
-  static const bool slabs_on = !(std::getenv("VOFOD_SLABS") && std::atoi(std::getenv("VOFOD_SLABS")) == 0);
+  const bool slabs_on = !switch_off("VOFOD_SLABS");
   constexpr uint32_t SLAB_MAX = 32;
   const uint32_t n_slabs = (ws.words_cap + SLAB_WORDS64 - 1) / SLAB_WORDS64;
   if (slabs_on && n >= 4 && !want_ptrank && !bricks && n_slabs <= SLAB_MAX)  // a single frame is served faster by the whole chip through the global bitmap
@@ -1094,7 +1108,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
     const uint32_t gk = std::max(1u, (max_pts + KEY_THREADS * KEY_PPT - 1) / (KEY_THREADS * KEY_PPT));
     KLAUNCH(h, k_key, fgrid(g, gk), dim3(KEY_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
     // VOFOD_SLAB_EMIT=0 keeps the separate emission kernels for every batch size
-    static const bool slab_emit_on = !(std::getenv("VOFOD_SLAB_EMIT") && std::atoi(std::getenv("VOFOD_SLAB_EMIT")) == 0);
+    const bool slab_emit_on = !switch_off("VOFOD_SLAB_EMIT");
     ws.bitmap_clean = false;
     unsigned long long*& d_prof_se = h->d_prof_slab;  // VOFOD_LDS_PROF=1 (diagnostics): per-handle stamp buffer
     if (!d_prof_se && std::getenv("VOFOD_LDS_PROF"))
@@ -1269,7 +1283,7 @@ int cluster_tables(vofod_handle* h, const GridParams& g, float tol, float cmax, 
 // voxel-level kernels (the tests compare both families against the oracle)
 bool want_bricks(const vofod_handle::ClusterTables* ct, const Workspace& ws)
 {
-  static const char* force = std::getenv("VOFOD_CCL");
+  const char* force = std::getenv("VOFOD_CCL");
   if (force && std::strcmp(force, "voxel") == 0)
     return false;
   return ct->brick_ok && ws.bricks_cap > 0;
@@ -1279,7 +1293,7 @@ bool want_bricks(const vofod_handle::ClusterTables* ct, const Workspace& ws)
 // per-root statistics slots to that kernel.  VOFOD_BRICK_LDS=0 keeps the global-memory kernels.
 bool plan_lds_ccl(const vofod_handle* h, const vofod_handle::ClusterTables* ct, const Workspace& ws, bool allow_lds)
 {
-  static const bool lds_on = !(std::getenv("VOFOD_BRICK_LDS") && std::atoi(std::getenv("VOFOD_BRICK_LDS")) == 0);
+  const bool lds_on = !switch_off("VOFOD_BRICK_LDS");
   return allow_lds && lds_on && want_bricks(ct, ws) && ct->lds_ok && !h->lds_ccl_off;
 }
 
@@ -1301,7 +1315,7 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     bp.bricks_cap = ws.bricks_cap;
     // Batches of independent frames: the whole brick graph of a frame is clustered inside one workgroup's LDS
     // (kernels_brick_lds.h).  VOFOD_BRICK_LDS=0 keeps the global-memory kernels.
-    static const uint32_t lb_limit = std::getenv("VOFOD_LDS_MAX_BRICKS") ? std::min<uint32_t>(LB_MAX, std::atoi(std::getenv("VOFOD_LDS_MAX_BRICKS"))) : LB_MAX;
+    const uint32_t lb_limit = std::getenv("VOFOD_LDS_MAX_BRICKS") ? std::min<uint32_t>(LB_MAX, std::atoi(std::getenv("VOFOD_LDS_MAX_BRICKS"))) : LB_MAX;
     if (ws.lean_emit)
     {
       (void)allow_lds;
@@ -1779,13 +1793,23 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       staged_2d = true;
     }
   }
+  bool host_copies = staged_2d;
   for (uint32_t f = 0; f < n && !rerun && !staged_2d; f++)
   {
     const vofod_scan& s = scans[f];
+    host_copies |= s.memspace != VOFOD_MEM_DEVICE;
     const int r = stage_cloud(h, ws, f, s.x, s.y, s.z, nullptr, nullptr, s.stride_bytes, npts, s.memspace, FA_SCAN, tfs + 12 * f);
     if (r != VOFOD_OK)
       return r;
   }
+  // include/vofod.h promises that the scans' host buffers need not outlive vofod_batch_submit.  A copy from page-locked memory
+  // is truly asynchronous - and on the streaming stage's stream it is queued behind the previous batch's streaming kernels:
+  // it may start long after the call has returned, when a caller that refills its arena has already overwritten it.
+  // The event marks the end of the batch's copies; the submitting call returns behind it (below).
+  if (host_copies && phase == FRAMES_LAUNCH && ws.ev_h2d)
+    HIPCHK(hipEventRecord(ws.ev_h2d, h->stream));
+  else
+    host_copies = false;
   const float leaf[3] = {sp.voxel_size, sp.voxel_size, sp.voxel_size};
   const int zero[3] = {0, 0, 0};
   float align_center[3];
@@ -1811,7 +1835,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   }
   CloseParams cpar{h->closetab.n_rows, thr_new};
   // read-only batches: the map's dilated image answers hasCloseTo with one bit per voxel (VOFOD_DILATE=0: stencil sweep)
-  static const bool dilate_on = !(std::getenv("VOFOD_DILATE") && std::atoi(std::getenv("VOFOD_DILATE")) == 0);
+  const bool dilate_on = !switch_off("VOFOD_DILATE");
   const bool use_dilated = dilate_on && no_update && n >= 4;
   if (use_dilated)
   {
@@ -1865,7 +1889,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // Read-only batches cluster close first (k_frame_lds): only the far clusters are ever used (vofod_nodelet.cpp:946-963).  The
   // debug view of ALL clusters keeps the full clustering; dbg[0].far_only asks for the production path's view instead.
   // VOFOD_CLOSE_FIRST=0: the full clustering everywhere.
-  static const bool close_first_on = !(std::getenv("VOFOD_CLOSE_FIRST") && std::atoi(std::getenv("VOFOD_CLOSE_FIRST")) == 0);
+  const bool close_first_on = !switch_off("VOFOD_CLOSE_FIRST");
   const bool dbg_far_only = dbg && dbg[0].far_only;
   if (h->cf_off && (h->n_bg_voxels > h->cf_off_bg + h->cf_off_bg / 4 + 1000 || h->n_bg_voxels < h->cf_off_bg))
     h->cf_off = false;  // the map has changed a lot since: try the close-first kernel again
@@ -1898,8 +1922,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     KLAUNCH(h, k_finalize, fgrid(g, gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, ws.d_labels, h->d_map, h->d_flags, ws.d_table, ws.d_cand, keep_dirty ? nullptr : ws.d_bitmaps);
   ws.bitmap_clean = frame_path ? bitmap_was_clean : !keep_dirty;
   ws.finalize_fused = false;
-  static const bool lite_on = !(std::getenv("VOFOD_LITE") && std::atoi(std::getenv("VOFOD_LITE")) == 0);
-  static const bool dtail_on = !(std::getenv("VOFOD_DEVICE_TAIL") && std::atoi(std::getenv("VOFOD_DEVICE_TAIL")) == 0);
+  const bool lite_on = !switch_off("VOFOD_LITE");
+  const bool dtail_on = !switch_off("VOFOD_DEVICE_TAIL");
   ws.dtail = dtail_on && !dbg && n >= 4 && no_update;
   ws.lite = !ws.dtail && lite_on && !dbg && n >= 4 && no_update;
   hipStream_t tail_stream_used = h->stream;  // where the device tail's last operation was enqueued
@@ -2011,6 +2035,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   tr_launch = ms_since(t0);
   if (phase == FRAMES_LAUNCH)
   {
+    if (host_copies)
+      HIPCHK(hipEventSynchronize(ws.ev_h2d));  // (the whole chain is enqueued by now: the device works while the host waits for the link)
     HIPCHK(hipEventRecord(ws.ev_done, ws.dtail ? tail_stream_used : ws.lite ? ws.copy_stream : h->stream));
     ws.pending = true;
     ws.job_n = n;
@@ -2348,7 +2374,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
 
   tr_prep = ms_since(t0);
   std::vector<vc::ExploreResult> results(jobs.size());
-  static const bool force_host = std::getenv("VOFOD_EXPLORE") && std::strcmp(std::getenv("VOFOD_EXPLORE"), "host") == 0;  // tests exercise the fallback
+  const bool force_host = std::getenv("VOFOD_EXPLORE") && std::strcmp(std::getenv("VOFOD_EXPLORE"), "host") == 0;  // tests exercise the fallback
   bool any_host = force_host;
   for (const FrameTail& T : tails)
     any_host |= T.host_fallback;

@@ -228,6 +228,10 @@ class VoFOD:
             return out, per, [self._dbg_dict(dbgs[f], bufs[f]) for f in range(n)]
         return out, per
 
+    def reserve(self, tickets: int):
+        """allocate the workspaces of `tickets` batches in flight now instead of inside the first submits"""
+        self._check(self.lib.reserve(self.h, int(tickets)), "vofod_reserve")
+
     def batch_submit(self, scans: Sequence[ScanData], tfs: np.ndarray) -> int:
         """Enqueue a batch (read-only map); returns the ticket for `batch_collect`.  At most eight in flight."""
         n = len(scans)
