@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--map-warm-scans", type=int, default=96)
     ap.add_argument("--cpu-baseline-scans", type=int, default=512, help="scans timed through the CPU oracle (0 disables); ~10 s of single-thread CPU work")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--loaded-tail-steps", type=int, default=40, help="steps of the loaded-tail leg (a scene with 12 floating targets: >= 50 detections per step); 0 disables")
     ap.add_argument("--host-input-steps", type=int, default=12, help="steps of the host-resident input leg (pinned host columns, VOFOD_MEM_HOST: the nodelet's operating point); 0 disables")
     ap.add_argument("--inflight", type=int, default=0, help="batches in flight (1..8; 0 = four for batches of 128 frames and more - the submission of batch k+1 then never waits for the tail of batch k-2, more gain nothing - and eight for smaller batches, whose whole chains run side by side); their kernel chains run on streams of their own and overlap on the device")
     ap.add_argument("--collective", choices=("torch", "cabi"), default="torch", help="N > 1: all-gather through torch.distributed (RCCL / gloo) or through the product's C-ABI (vofod_allgather_detections: RCCL from libvofod_hip.so)")
@@ -102,11 +103,14 @@ def stub_rank(args):
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
-    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+    if not args.rehearse_one_gpu:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # (as main() does before anything initialises the GPU)
+    seen = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank, int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))], dtype=torch.int64))
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"stub": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks_seen": [int(t.item()) for t in seen], "local_rank": int(os.environ["LOCAL_RANK"])}))
+        print(json.dumps({"stub": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks_seen": [int(t[0].item()) for t in seen], "hw_queues_seen": [int(t[1].item()) for t in seen],
+                          "local_rank": int(os.environ["LOCAL_RANK"])}))
     dist.destroy_process_group()
 
 
@@ -119,13 +123,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if not args.rehearse_one_gpu:
         # The library keeps up to a dozen HIP streams busy (key / frame / tail stages, one chain per small batch in flight); the
         # runtime deals a process's streams onto FOUR hardware queues by default, and streams that share a queue take turns (32-frame
         # batches: 131 k -> 227 k frames/s from this variable alone; 256-frame batches: no difference).  Read by the runtime when it
-        # initialises, i.e. before the first HIP call of the process.  Only where ONE process owns the GPU: two
-        # processes with sixteen queues each on one card (the gloo rehearsal of the N > 1 path) take turns on the hardware's
-        # queue slots - 54 k instead of 382 k frames/s - and the multi-GPU runs keep the runtime's default until measured.
+        # initialises, i.e. before the first HIP call of the process.  Every rank that OWNS its GPU asks for them
+        # (round 4: a real multi-GPU run used to keep the default of four and would have run its 32-frame share at the ~140 k
+        # frames/s of four queues); only the gloo rehearsal of the N > 1 path on ONE card keeps the default: two processes with
+        # sixteen queues each take turns on the hardware's queue slots - 54 k instead of 382 k frames/s.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
@@ -158,18 +163,24 @@ def main():
     # F independent frames per rank (seeds differ per rank), resident in HBM as packed SoA columns
     h, w, _, _ = synth.SENSORS[args.sensor]
     n_pts = h * w
+    def resident(frames_):
+        """a set of frames as packed SoA columns in HBM"""
+        c = torch.empty((len(frames_), 3, n_pts), dtype=torch.float32, device=dev)
+        for f, s in enumerate(frames_):
+            c[f, 0] = torch.from_numpy(s.x)
+            c[f, 1] = torch.from_numpy(s.y)
+            c[f, 2] = torch.from_numpy(s.z)
+        sc = [ScanData(x=c[f, 0].data_ptr(), y=c[f, 1].data_ptr(), z=c[f, 2].data_ptr(), width=w, height=h, stride_bytes=4, memspace=capi.MEM_DEVICE) for f in range(len(frames_))]
+        return c, sc, np.stack([s.tf for s in frames_]).astype(np.float32)
+
     host_scans = synth.bench_frames(scene, args.sensor, F, rank)
-    cols = torch.empty((F, 3, n_pts), dtype=torch.float32, device=dev)
-    for f, s in enumerate(host_scans):
-        cols[f, 0] = torch.from_numpy(s.x)
-        cols[f, 1] = torch.from_numpy(s.y)
-        cols[f, 2] = torch.from_numpy(s.z)
+    cols, scans, tfs = resident(host_scans)
+    # a second, different set of F frames (other poses, other noise): the timed loop alternates between the two, so that no step
+    # finds its 402 MB of input in the 256 MB Infinity Cache from the step before (VERDICT r3 #11)
+    host_scans_b = synth.bench_frames(scene, args.sensor, F, rank + 5000)
+    cols_b, scans_b, tfs_b = resident(host_scans_b)
     torch.cuda.synchronize()
-    scans = [
-        ScanData(x=cols[f, 0].data_ptr(), y=cols[f, 1].data_ptr(), z=cols[f, 2].data_ptr(), width=w, height=h, stride_bytes=4, memspace=capi.MEM_DEVICE)
-        for f in range(F)
-    ]
-    tfs = np.stack([s.tf for s in host_scans]).astype(np.float32)
+    input_sets = [(scans, tfs), (scans_b, tfs_b)]
 
     from vofod_amd import dist as vdist
 
@@ -199,7 +210,7 @@ def main():
             b["local"].copy_(rec_host, non_blocking=True)
             vdist.allgather_detections(b["local"], b["all"])
 
-    def run_steps(k, scans=scans, tfs=tfs):
+    def run_steps(k, scans=None, tfs=None):
         """k batches through the submit/collect pipeline: batch i+1 is enqueued before batch i is collected, so the host
         tail of one batch overlaps the device chain of the next.  Every batch is submitted and collected inside the call."""
         n_det = 0
@@ -207,9 +218,10 @@ def main():
         host_prof = os.environ.get("VOFOD_BENCH_HOSTPROF") == "1"  # diagnostics: where the host thread spends a step
         step_log = [] if os.environ.get("VOFOD_BENCH_STEPLOG") == "1" else None  # diagnostics: completion time of every step
         t_sub = t_col = 0.0
-        for _ in range(k):
+        for i in range(k):
             ta = time.perf_counter()
-            inflight.append(det.batch_submit(scans, tfs))
+            sc_i, tf_i = (scans, tfs) if scans is not None else input_sets[i & 1]
+            inflight.append(det.batch_submit(sc_i, tf_i))
             tb = time.perf_counter()
             if len(inflight) == args.inflight:
                 dets, per = det.batch_collect(inflight.pop(0))
@@ -242,7 +254,8 @@ def main():
 
     gc.collect()
     gc.freeze()
-    gc.disable()
+    if os.environ.get("VOFOD_BENCH_GC") != "on":  # (tools/transient.sh compares both)
+        gc.disable()
     if args.warmup:
         run_steps(args.warmup)
     sync()
@@ -254,6 +267,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    gc.enable()  # the timed region is over: the legs below (and the CPU baseline) run with the collector as usual
 
     # configs[3] as written: 256 scans per step in total, split over the ranks (strong scaling), all-gather included.  On one
     # GPU this is the headline run itself; on N GPUs every rank takes the first 256 / N of its frames.
@@ -274,6 +288,17 @@ def main():
         strong = {"frames_total_per_step": world * Fs, "frames_per_gpu_per_step": Fs, "frames_per_s": world * Fs * args.steps / dts, "ms_per_step": 1e3 * dts / args.steps,
                   "note": "configs[3]: 256 scans per step split over the GPUs (strong scaling), detections all-gathered every step"}
 
+    # proof that the collective saw every rank (the first real multi-GPU record should show N ranks over RCCL, not N replicas)
+    ranks_seen, rccl_version = [0], None
+    if world > 1:
+        rs = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(rs, torch.tensor([rank], dtype=torch.int64, device=cdev))
+        ranks_seen = [int(t.item()) for t in rs]
+        if args.backend == "nccl":
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                rccl_version = "unknown"
     out = None
     if rank == 0:
         frames = world * F * args.steps
@@ -305,8 +330,12 @@ def main():
                 "map_warm_scans": args.map_warm_scans,
                 "detections_per_step": n_det / args.steps,
                 "pipeline": f"vofod_batch_submit/collect, {args.inflight} batches in flight on streams of their own; classification tail on the device",
+                "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) or "runtime default (4)",
             },
         }
+        if world > 1:
+            out["ranks_seen"] = ranks_seen
+            out["collective"] = {"caller": args.collective, "backend": args.backend, "rccl_version": rccl_version}
         if strong is not None:
             out["config3_strong"] = strong
         elif world == 1 and F == 256 and args.scaling == "weak":
@@ -362,8 +391,23 @@ def main():
             out["config3_share"] = {"frames_per_gpu_per_step": 32, "frames_per_s": 32 * 100 / dt32, "ms_per_step": 1e3 * dt32 / 100, "kernel_us": k32,
                                     "batches_in_flight": depth32,
                                     "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU, eight in flight, each on a stream (and hardware queue) of its own with its own tail; a frame kernel of 32 workgroups leaves 7/8 of the CUs to the other batches in flight"}
+        if world == 1 and args.loaded_tail_steps > 0:
+            # the classification tail under load: twelve floating targets, nine of which appeared after the map was warmed
+            # (the headline scene's three are part of the background by now: ~3 detections per step leave the tail nearly idle)
+            busy = synth.make_scene(synth.BENCH_SCENE_SEED, n_targets=12)
+            _, scans_t, tfs_t = resident(synth.bench_frames(busy, args.sensor, F, rank))
+            run_steps(3, scans_t, tfs_t)
+            sync()
+            t1 = time.perf_counter()
+            nd = run_steps(args.loaded_tail_steps, scans_t, tfs_t)
+            sync()
+            dtl = time.perf_counter() - t1
+            out["loaded_tail"] = {"frames_per_s": F * args.loaded_tail_steps / dtl, "ms_per_step": 1e3 * dtl / args.loaded_tail_steps, "steps": args.loaded_tail_steps,
+                                  "detections_per_step": nd / args.loaded_tail_steps,
+                                  "note": "the same pipeline on a scene with 12 floating targets (9 new since the warm-up): dozens of candidate clusters, flood fills and detections per batch"}
         if world == 1 and args.host_input_steps > 0:
             out["host_input"] = host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w)
+            out["host_input_aos"] = host_input_aos_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w)
         if not args.no_profile_pass:
             out["roofline"], out["kernels"] = profile_pass(lib, det, scans, tfs, n_pts, V, F, V_far)
             # the same bytes over the pipelined step time of this rank (kernels of consecutive batches overlap: the step is
@@ -422,6 +466,49 @@ def host_input_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w):
         "h2d_GBps": nbytes * args.host_input_steps / dt / 1e9,
         "note": "pinned host x|y|z columns (12 B/point), VOFOD_MEM_HOST, one hipMemcpy2DAsync per batch overlapped with the previous batch's chain; bound by the host link "
         "(PCIe Gen5 x16: 64 GB/s raw, ~50-55 GB/s achievable = ~33-36 k frames/s of 1.57 MB); the 48-byte ouster AoS of the nodelet would move 4x the bytes",
+    }
+
+
+def host_input_aos_leg(args, det, host_scans, tfs, torch, capi, ScanData, h, w):
+    """What the nodelet really holds: pcl::PointCloud<ouster_ros::Point> - 48-byte structs (x, y, z at bytes 0 / 4 / 8;
+    include/vofod/point_types.h), host resident.  The library moves each frame's block with one copy and reads the columns in
+    place at the struct's stride: 4 x the bytes of packed columns over the link."""
+    F = len(host_scans)
+    n_pts = h * w
+    POINT = 48
+    arena = torch.zeros((F, n_pts, POINT // 4), dtype=torch.float32).pin_memory()
+    for f, s in enumerate(host_scans):
+        arena[f, :, 0] = torch.from_numpy(s.x)
+        arena[f, :, 1] = torch.from_numpy(s.y)
+        arena[f, :, 2] = torch.from_numpy(s.z)
+    base = arena.data_ptr()
+    hs = [ScanData(x=base + f * n_pts * POINT, y=base + f * n_pts * POINT + 4, z=base + f * n_pts * POINT + 8, width=w, height=h, stride_bytes=POINT, memspace=capi.MEM_HOST) for f in range(F)]
+    steps = max(2, args.host_input_steps // 3)
+
+    def run(k):
+        infl = []
+        for _ in range(k):
+            infl.append(det.batch_submit(hs, tfs))
+            if len(infl) == 2:
+                det.batch_collect(infl.pop(0))
+        while infl:
+            det.batch_collect(infl.pop(0))
+
+    run(2)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    nbytes = float(POINT) * n_pts * F
+    return {
+        "frames_per_s": F * steps / dt,
+        "ms_per_step": 1e3 * dt / steps,
+        "steps": steps,
+        "h2d_bytes_per_step": nbytes,
+        "h2d_GBps": nbytes * steps / dt / 1e9,
+        "note": "pinned host array of 48-byte ouster_ros::Point structs (the nodelet's own cloud), VOFOD_MEM_HOST, one copy per frame, columns read in place at stride 48; "
+        "PCIe ceiling for this layout: ~50-55 GB/s / 6.3 MB = ~8-9 k frames/s",
     }
 
 

@@ -406,6 +406,12 @@ int vofod_comm_unique_id(uint8_t id[VOFOD_COMM_ID_BYTES]);
 int vofod_comm_create(const uint8_t id[VOFOD_COMM_ID_BYTES], int32_t rank, int32_t n_ranks, int32_t device, vofod_comm** out);
 void vofod_comm_destroy(vofod_comm* comm);
 const char* vofod_comm_last_error(vofod_comm* comm);
+/* The exchange's wire format as plain host functions (no device, no communicator): a caller with a transport of its own (MPI,
+ * gloo) packs, all-gathers `frames * vofod_detection_slot_bytes(d_max)` bytes per rank and unpacks.  Slot of a frame: d_max
+ * records of 128 bytes (the frame's first detections in order, zero padded) followed by the frame's true count (8 bytes). */
+size_t vofod_detection_slot_bytes(size_t d_max);
+int vofod_pack_detection_slots(const vofod_detection* local, const uint32_t* n_per_frame, size_t frames, size_t d_max, void* slots);
+int vofod_unpack_detection_slots(const void* slots, size_t frames_total, size_t d_max, vofod_detection* all, uint32_t* all_counts);
 /* local: this rank's detections in frame order (what vofod_process_batch / vofod_batch_collect returned), n_per_frame: their
  * count per frame.  all: n_ranks * frames_per_rank * d_max records, slot (rank, frame) holds min(count, d_max) records;
  * all_counts: n_ranks * frames_per_rank counts (a count above d_max tells that the slot was truncated). */

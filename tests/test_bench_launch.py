@@ -24,6 +24,15 @@ def test_gpus_flag_starts_that_many_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["gpus_arg"] == 2
     assert d["ranks_seen"] == [0, 1]
+    # every rank that owns its GPU asks the runtime for 16 hardware queues before anything initialises it (bench.py main())
+    assert d["hw_queues_seen"] == [16, 16]
+
+
+def test_the_one_gpu_rehearsal_keeps_the_default_queues():
+    r = _run({"VOFOD_BENCH_STUB": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-one-gpu", "--backend", "gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["hw_queues_seen"] == [0, 0]
 
 
 def test_launcher_env_wins_over_the_flag():

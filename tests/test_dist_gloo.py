@@ -78,6 +78,58 @@ def test_pack_unpack_roundtrip():
     d["confidence"] = [0.5, 0.25, 1.0]
     d["position"] = np.arange(9).reshape(3, 3)
     packed = vdist.pack_detections(d, np.array([1, 0, 2], dtype=np.uint32))
-    assert packed.shape == (3, vdist.FRAME_F64) and packed[:, -1].tolist() == [1, 0, 2]
+    assert packed.shape == (3, vdist.FRAME_F64) and packed.view(np.uint64)[:, -1].tolist() == [1, 0, 2]
     back = vdist.unpack_detections(packed)
     assert back.tobytes() == d.tobytes()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 8])
+def test_cabi_slot_pack_unpack_matches_the_python_caller(n_ranks):
+    """vofod_allgather_detections' pack / unpack loops (collective.h), as the plain host functions they are: byte for byte the
+    payload vofod_amd/dist.py builds, for 2 and 8 ranks, with a frame whose detections exceed d_max (truncated slot, true
+    count kept) and ranks without any detection.  The all-gather itself is a concatenation of the ranks' buffers."""
+    import ctypes as C
+
+    import vofod_amd
+    from vofod_amd import capi, dist as vdist
+
+    lib = vofod_amd.library()  # host functions only: no GPU needed
+    rng = np.random.default_rng(n_ranks)
+    frames, d_max = 5, vdist.D_MAX
+    slot = lib.detection_slot_bytes(d_max)
+    assert slot == d_max * 128 + 8 == vdist.FRAME_F64 * 8
+    wire, want, want_counts = [], [], []
+    for r in range(n_ranks):
+        per = rng.integers(0, 4, frames).astype(np.uint32)
+        if r == 1:
+            per[:] = 0  # a rank without detections
+        if r == 0:
+            per[2] = d_max + 3  # more than the slot holds
+        dets = np.zeros(int(per.sum()), dtype=capi.DETECTION)
+        dets["id"] = rng.integers(0, 1 << 31, len(dets))
+        dets["frame"] = np.repeat(np.arange(frames), per)
+        dets["n_points"] = rng.integers(1, 99, len(dets))
+        dets["confidence"] = rng.random(len(dets))
+        dets["position"] = rng.normal(size=(len(dets), 3))
+        buf = np.zeros(frames * slot, dtype=np.uint8)
+        st = lib.pack_detection_slots(capi.ptr(dets) if len(dets) else None, capi.ptr(per), frames, d_max, capi.ptr(buf))
+        assert st == capi.OK
+        assert buf.tobytes() == vdist.pack_detections(dets, per).tobytes()
+        wire.append(buf)
+        start = np.cumsum(per) - per
+        for f in range(frames):
+            blk = np.zeros(d_max, dtype=capi.DETECTION)
+            m = min(int(per[f]), d_max)
+            blk[:m] = dets[start[f] : start[f] + m]
+            want.append(blk)
+        want_counts.append(per)
+    gathered = np.concatenate(wire)
+    out = np.zeros(n_ranks * frames * d_max, dtype=capi.DETECTION)
+    counts = np.zeros(n_ranks * frames, dtype=np.uint32)
+    assert lib.unpack_detection_slots(capi.ptr(gathered), n_ranks * frames, d_max, capi.ptr(out), capi.ptr(counts)) == capi.OK
+    assert out.tobytes() == np.concatenate(want).tobytes()
+    np.testing.assert_array_equal(counts, np.concatenate(want_counts))
+    assert counts[2] == d_max + 3  # the truncated slot still tells its true count
+    # argument checks
+    assert lib.pack_detection_slots(None, capi.ptr(np.ones(1, dtype=np.uint32)), 1, d_max, capi.ptr(np.zeros(slot, dtype=np.uint8))) == capi.ERR_INVALID_ARG
+    assert lib.unpack_detection_slots(None, 1, d_max, capi.ptr(out), capi.ptr(counts)) == capi.ERR_INVALID_ARG

@@ -5,7 +5,7 @@ TAG=${1:-tr}
 O=gpurun_out/$TAG; mkdir -p $O
 for i in 1 2; do
   VOFOD_BENCH_STEPLOG=1 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline-scans 0 --no-profile-pass > $O/drv_$i.json 2> $O/drv_$i.err || exit 1
-  VOFOD_BENCH_GC=off VOFOD_BENCH_STEPLOG=1 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline-scans 0 --no-profile-pass > $O/gcoff_$i.json 2> $O/gcoff_$i.err || exit 1
+  VOFOD_BENCH_GC=on VOFOD_BENCH_STEPLOG=1 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline-scans 0 --no-profile-pass > $O/gcon_$i.json 2> $O/gcon_$i.err || exit 1
 done
 grep -H steps $O/*.err
 python3 -c "

@@ -241,6 +241,9 @@ _SIGS = {
     "comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _P(C.c_void_p)]),
     "comm_destroy": (None, [C.c_void_p]),
     "comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "detection_slot_bytes": (C.c_size_t, [C.c_size_t]),
+    "pack_detection_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "unpack_detection_slots": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "allgather_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "voxels_as_pc": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "update_ground": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
@@ -266,7 +269,7 @@ _SIGS = {
 
 
 # entry points only the product library has to export (include/vofod.h says so)
-PRODUCT_ONLY = ("comm_unique_id", "comm_create", "comm_destroy", "comm_last_error", "allgather_detections", "serialize_detections", "serialize_status",
+PRODUCT_ONLY = ("comm_unique_id", "comm_create", "comm_destroy", "comm_last_error", "allgather_detections", "detection_slot_bytes", "pack_detection_slots", "unpack_detection_slots", "serialize_detections", "serialize_status",
                 "serialize_profiling_info")
 
 

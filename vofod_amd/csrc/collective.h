@@ -159,6 +159,53 @@ void vofod_comm_destroy(vofod_comm* c)
 
 const char* vofod_comm_last_error(vofod_comm* c) { return c ? c->err.c_str() : vcoll::api().err.c_str(); }
 
+// The exchange's wire format, as two plain host functions (no device, no communicator: unit-tested on the CPU for 2 and 8
+// ranks, byte for byte against vofod_amd/dist.py's pack_detections; a caller with a transport of its own - MPI, gloo - can use
+// them directly).  Slot of a frame: d_max records of 128 bytes (the frame's first detections in order, zero padded), then the
+// frame's TRUE count as a 64-bit word (D_max * 128 + 8 bytes).
+size_t vofod_detection_slot_bytes(size_t d_max) { return d_max * sizeof(vofod_detection) + 8; }
+
+int vofod_pack_detection_slots(const vofod_detection* local, const uint32_t* n_per_frame, size_t frames, size_t d_max, void* slots)
+{
+  if (!n_per_frame || !slots || d_max == 0)
+    return VOFOD_ERR_INVALID_ARG;
+  static_assert(sizeof(vofod_detection) == 128, "Detection.msg record: 128 bytes");
+  const size_t slot = vofod_detection_slot_bytes(d_max);
+  char* out = static_cast<char*>(slots);
+  std::memset(out, 0, frames * slot);
+  size_t next = 0;
+  for (size_t f = 0; f < frames; f++)
+  {
+    char* s = out + f * slot;
+    const uint32_t cnt = n_per_frame[f];
+    const uint32_t keep = static_cast<uint32_t>(std::min<size_t>(cnt, d_max));
+    if (keep)
+    {
+      if (!local)
+        return VOFOD_ERR_INVALID_ARG;
+      std::memcpy(s, local + next, keep * sizeof(vofod_detection));
+    }
+    std::memcpy(s + d_max * sizeof(vofod_detection), &cnt, 4);
+    next += cnt;
+  }
+  return VOFOD_OK;
+}
+
+int vofod_unpack_detection_slots(const void* slots, size_t frames_total, size_t d_max, vofod_detection* all, uint32_t* all_counts)
+{
+  if (!slots || !all || !all_counts || d_max == 0)
+    return VOFOD_ERR_INVALID_ARG;
+  const size_t slot = vofod_detection_slot_bytes(d_max);
+  const char* in = static_cast<const char*>(slots);
+  for (size_t q = 0; q < frames_total; q++)
+  {
+    const char* s = in + q * slot;
+    std::memcpy(all + q * d_max, s, d_max * sizeof(vofod_detection));
+    std::memcpy(all_counts + q, s + d_max * sizeof(vofod_detection), 4);
+  }
+  return VOFOD_OK;
+}
+
 int vofod_allgather_detections(vofod_comm* c, const vofod_detection* local, const uint32_t* n_per_frame, size_t frames_per_rank, size_t d_max, vofod_detection* all, uint32_t* all_counts)
 {
   if (!c || !n_per_frame || !all || !all_counts || d_max == 0)
@@ -171,7 +218,7 @@ int vofod_allgather_detections(vofod_comm* c, const vofod_detection* local, cons
   if (hipSetDevice(c->device) != hipSuccess)
     return VOFOD_ERR_DEVICE;
   static_assert(sizeof(vofod_detection) == 128, "Detection.msg record: 128 bytes");
-  const size_t slot = d_max * sizeof(vofod_detection) + 8;  // records + count word per frame
+  const size_t slot = vofod_detection_slot_bytes(d_max);  // records + count word per frame
   const size_t bytes = frames_per_rank * slot;
   if (bytes == 0)
     return VOFOD_OK;
@@ -200,18 +247,8 @@ int vofod_allgather_detections(vofod_comm* c, const vofod_detection* local, cons
     c->cap_bytes = bytes;
   }
   // pack: the frame's detections (in order) at the head of its slot, the count behind them
-  std::memset(c->h_stage, 0, bytes);
-  size_t next = 0;
-  for (size_t f = 0; f < frames_per_rank; f++)
-  {
-    char* s = c->h_stage + f * slot;
-    const uint32_t cnt = n_per_frame[f];
-    const uint32_t keep = static_cast<uint32_t>(std::min<size_t>(cnt, d_max));
-    if (keep)
-      std::memcpy(s, local + next, keep * sizeof(vofod_detection));
-    std::memcpy(s + d_max * sizeof(vofod_detection), &cnt, 4);
-    next += cnt;
-  }
+  if (const int pr = vofod_pack_detection_slots(local, n_per_frame, frames_per_rank, d_max, c->h_stage); pr != VOFOD_OK)
+    return pr;
   COLLCHK(hipMemcpyAsync(c->d_send, c->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
   if (const int r = vcoll::api().AllGather(c->d_send, c->d_recv, bytes, 0 /* ncclChar */, c->comm, c->stream); r != 0)
   {
@@ -222,12 +259,8 @@ int vofod_allgather_detections(vofod_comm* c, const vofod_detection* local, cons
   COLLCHK(hipMemcpyAsync(h_recv, c->d_recv, bytes * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   COLLCHK(hipStreamSynchronize(c->stream));
 #undef COLLCHK
-  for (size_t q = 0; q < static_cast<size_t>(c->n_ranks) * frames_per_rank; q++)
-  {
-    const char* s = h_recv + q * slot;
-    std::memcpy(all + q * d_max, s, d_max * sizeof(vofod_detection));
-    std::memcpy(all_counts + q, s + d_max * sizeof(vofod_detection), 4);
-  }
+  if (const int ur = vofod_unpack_detection_slots(h_recv, static_cast<size_t>(c->n_ranks) * frames_per_rank, d_max, all, all_counts); ur != VOFOD_OK)
+    return ur;
   return VOFOD_OK;
 }
 

@@ -296,6 +296,9 @@ struct Workspace
   RefLattice ref_lattice{};  // single-pass input: the reference lattice the list's cells refer to (on = 0: brick codes from k_key2)
   bool frame_fused = false;  // k_key2 ran: launch_cluster runs k_frame_lds (voxel records + clustering in one kernel)
   float* d_stage = nullptr;  // F * pt_cap * 5 words: x, y, z, intensity, range of host-resident inputs
+  char* d_stage_aos = nullptr;  // host-resident array-of-structs clouds (the nodelet's 48-byte ouster_ros::Point) cross the link as they are:
+  size_t stage_aos_bytes = 0;   // F * aos_pitch bytes, allocated on first use; the kernels read x / y / z in place at the struct's stride
+  size_t aos_pitch = 0;
   PackedFrame* d_packed = nullptr;
   PackedFrame* h_packed = nullptr;  // pinned
   PackedLite* d_lite = nullptr;
@@ -354,6 +357,10 @@ struct Workspace
 
   void release()
   {
+    if (d_stage_aos)
+      (void)hipFree(d_stage_aos);
+    d_stage_aos = nullptr;
+    stage_aos_bytes = 0;
     void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
     for (void* p : ptrs)
       if (p)
@@ -964,6 +971,43 @@ int stage_cloud(vofod_handle* h, Workspace& ws, uint32_t f, const void* x, const
     a.intensity = static_cast<const char*>(intensity);
     a.stride = stride;
     return VOFOD_OK;
+  }
+  // An array of structs in host memory (stride > 4, the three coordinates inside one struct: pcl::PointCloud<ouster_ros::Point>,
+  // 48 bytes per point, what the nodelet holds - include/vofod/point_types.h) crosses the link with ONE copy of the whole block;
+  // the kernels then read the columns in place at the struct's stride (k_key1<false>).  Round 3 gathered every column on the
+  // host (three passes over the cloud and a synchronisation per column: ~1 ms per frame).  4 x the bytes of packed columns over
+  // PCIe: the link's ceiling for this layout is ~8 k frames/s of OS1-128.
+  if (stride > 4 && !intensity && !range && n > 0)
+  {
+    const char* lo = std::min({static_cast<const char*>(x), static_cast<const char*>(y), static_cast<const char*>(z)});
+    const char* hi = std::max({static_cast<const char*>(x), static_cast<const char*>(y), static_cast<const char*>(z)});
+    if (static_cast<size_t>(hi - lo) + 4 <= stride)
+    {
+      const size_t block = (n - 1) * stride + static_cast<size_t>(hi - lo) + 4;
+      const size_t pitch = (ws.pt_cap * stride + 255) & ~static_cast<size_t>(255);
+      if (ws.aos_pitch != pitch || ws.stage_aos_bytes < pitch * ws.F)
+      {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (ws.d_stage_aos)
+          (void)hipFree(ws.d_stage_aos);
+        ws.d_stage_aos = nullptr;
+        ws.stage_aos_bytes = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&ws.d_stage_aos), pitch * ws.F));
+        ws.stage_aos_bytes = pitch * ws.F;
+        ws.aos_pitch = pitch;
+      }
+      if (block <= pitch)
+      {
+        char* dst = ws.d_stage_aos + static_cast<size_t>(f) * pitch;
+        HIPCHK(hipMemcpyAsync(dst, lo, block, hipMemcpyHostToDevice, h->stream));
+        a.x = dst + (static_cast<const char*>(x) - lo);
+        a.y = dst + (static_cast<const char*>(y) - lo);
+        a.z = dst + (static_cast<const char*>(z) - lo);
+        a.intensity = nullptr;
+        a.stride = stride;
+        return VOFOD_OK;
+      }
+    }
   }
   float* base = ws.d_stage + static_cast<size_t>(f) * ws.pt_cap * 5;
   const void* cols[5] = {x, y, z, intensity, range};

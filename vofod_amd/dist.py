@@ -30,7 +30,7 @@ def pack_detections(dets: np.ndarray, per_frame: np.ndarray, out: np.ndarray | N
     else:
         out[:] = 0
     per_frame = np.asarray(per_frame)
-    out[:, -1] = per_frame
+    out.view(np.uint64)[:, -1] = per_frame  # the count as an integer word: the same bytes as vofod_pack_detection_slots (collective.h) writes
     if len(dets):
         raw = np.ascontiguousarray(dets).view(np.float64).reshape(-1, REC_F64)
         start = np.cumsum(per_frame) - per_frame  # first record of every frame
@@ -44,7 +44,7 @@ def unpack_detections(packed: np.ndarray, frame_offset: int = 0) -> np.ndarray:
     """Inverse of pack_detections for one rank's block; `frame` fields are rebased by frame_offset."""
     recs = []
     for f in range(packed.shape[0]):
-        m = min(int(packed[f, -1]), D_MAX)
+        m = min(int(np.ascontiguousarray(packed).view(np.uint64)[f, -1]), D_MAX)
         if m:
             d = np.frombuffer(np.ascontiguousarray(packed[f, : m * REC_F64]).tobytes(), dtype=capi.DETECTION).copy()
             d["frame"] = frame_offset + f
