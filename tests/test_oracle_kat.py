@@ -545,3 +545,23 @@ def test_check_sensor_params(oracle):
     assert check_sensor_params(oracle, scan_of(xyz + offs, rng_mm), lut, lut_offsets=offs) == (True, True)
     # no valid pixel at all: nothing checked, parameters not rejected
     assert check_sensor_params(oracle, scan_of(xyz, np.zeros(h * w, np.uint32)), lut) == (True, False)
+
+
+@pytest.mark.parametrize("n_its", [0, 1, 3])
+def test_sepclusters_two_islands_by_hand(oracle, n_its):
+    """updateSeparatedBGClusters (vofod_nodelet.cpp:1126-1277) on a 9^3 toy map: leaf, positional counts (Q1), sums per
+    cluster, the latch, the truncated-norm erase stencil around cast<int> centres, the erase weight after 0 (-> 1), 1 and 3
+    detection iterations - tests/kat_cases.py derives every number from the cited lines"""
+    import kat_cases
+
+    kat_cases.sepclusters_case(oracle, n_its)
+
+
+@pytest.mark.parametrize("new_rule", [True, False])
+@pytest.mark.parametrize("n_its", [1, 3])
+def test_raycast_update_three_rays_by_hand(oracle, new_rule, n_its):
+    """raycast_cloud's accumulation and both update rules (vofod_nodelet.cpp:1455-1457, 1550-1604) on three axis rays with
+    hand-summed path lengths; flagged voxels untouched, flags cleared"""
+    import kat_cases
+
+    kat_cases.raycast_case(oracle, new_rule, n_its)
