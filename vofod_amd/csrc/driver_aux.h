@@ -1097,6 +1097,19 @@ int vofod_batch_submit(vofod_handle* h, const vofod_scan* scans, const float* tf
     h->err = "eight batches already in flight: collect one first";
     return VOFOD_ERR_CAPACITY;
   }
+  if (t >= 4)
+  {
+    // more than four chains in flight: they only run side by side when the runtime may use more than its default of four
+    // hardware queues (a process-wide setting read when the runtime initialises: INTEGRATION.md) - say so once
+    static std::once_flag warned;
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    if (!q || std::atoi(q) < 8)
+      std::call_once(warned, [] {
+        std::fprintf(stderr, "[vofod] more than four batches in flight but GPU_MAX_HW_QUEUES is %s: their streams share four hardware queues and take turns "
+                             "(32-frame batches: ~140 k instead of ~230 k frames/s); export GPU_MAX_HW_QUEUES=16 before the process starts\n",
+                     std::getenv("GPU_MAX_HW_QUEUES") ? std::getenv("GPU_MAX_HW_QUEUES") : "unset");
+      });
+  }
   Workspace* w = h->slot(t);
   if (w->F == 0)
   {

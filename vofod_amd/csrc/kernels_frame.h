@@ -345,7 +345,8 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
   float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
   uint32_t code[KEY1_PPT];
   uint32_t cnt = 0, frag_mask = 0;
-  uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their indices in the cloud
+  uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their transformed coordinates, 3 floats each
+  float sq0 = 0.0f, sq1 = 0.0f, sq2 = 0.0f;  // ... of the thread's FIRST fragile point (8 % of the threads have one, 0.3 % a second)
   // Branch-free per point: a value lies inside a closed interval iff the median of (value, low, high) is the value itself -
   // one v_med3 + one compare per axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed
   // point, which fails the operation-area test: the explicit isfinite() of the first crop is implied.
@@ -408,7 +409,12 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
       const bool solid = keep[e] & fits & (max3_abs(gmid[0][e], gmid[1][e], gmid[2][e]) <= solid_lim);
       cnt += solid ? 1u : 0u;
       code[j0 + e] = solid ? (k0 | (k1 << 11) | (k2 << 22)) : FR_CODE_NONE;
-      frag_mask |= (keep[e] & !solid) ? (1u << (j0 + e)) : 0u;  // kept aside by its index: k_frame_lds fetches the point again and encodes it exactly
+      const bool fragile = keep[e] & !solid;  // kept aside with its transformed coordinates: k_frame_lds encodes it with the frame's own offset
+      const bool first_fr = fragile & (frag_mask == 0u);
+      sq0 = first_fr ? q[0][e] : sq0;
+      sq1 = first_fr ? q[1][e] : sq1;
+      sq2 = first_fr ? q[2][e] : sq2;
+      frag_mask |= fragile ? (1u << (j0 + e)) : 0u;
     }
   }
   // bounding box of the block ...
@@ -487,11 +493,26 @@ __global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restri
       *out++ = code[j];
   if (frag_mask)
   {
-    uint32_t* fout = frag + s_fbase + foff;
+    // A fragile point leaves as its transformed coordinates (12 bytes), not as its index (round 3): the frame kernel then
+    // fetched x, y, z from the input columns again - ~550 random 4-byte reads per frame and column, 430 k random 64-byte DRAM
+    // accesses per batch at the moment all 256 workgroups start: 10-15 us at the head of every frame's critical path (measured:
+    // the same loop on sequential or cache-resident indices takes 2-3 us).  The first fragile point of a thread was kept in
+    // registers; a further one (0.3 % of the threads) is loaded again - its line is still in the cache - and transformed with the
+    // very expression of the loop above (packed or not, every operation rounds the same).
+    float* fout = reinterpret_cast<float*>(frag) + 3u * (s_fbase + foff);
+    fout[0] = sq0, fout[1] = sq1, fout[2] = sq2;
+    fout += 3;
+    uint32_t rest = frag_mask & (frag_mask - 1u);
+    while (rest)
+    {
+      const uint32_t pi = i0 + static_cast<uint32_t>(__ffs(static_cast<int>(rest)) - 1);
+      rest &= rest - 1u;
+      const uint64_t st = PACKED ? 4u : a.stride;
+      const float p0 = ldf(a.x, st, pi), p1 = ldf(a.y, st, pi), p2 = ldf(a.z, st, pi);
 #pragma unroll
-    for (int j = 0; j < KEY1_PPT; j++)
-      if ((frag_mask >> j) & 1u)
-        *fout++ = i0 + j;
+      for (int r = 0; r < 3; r++)
+        *fout++ = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
+    }
   }
 }
 
@@ -812,16 +833,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   // the reference cells in the list.
   auto fragile_points = [&]() {
     const uint32_t dst0 = n_ref;
-    const uint32_t* frag = sa.extras + static_cast<size_t>(SRC) * pt_cap;
-    const FrameArgs& fa = args[SRC];
+    const float* fq = reinterpret_cast<const float*>(sa.extras + static_cast<size_t>(SRC) * pt_cap);  // k_key1 left the transformed points
     for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
     {
-      const uint32_t pi = frag[i];
-      const float p0 = ldf(fa.x, fa.stride, pi), p1 = ldf(fa.y, fa.stride, pi), p2 = ldf(fa.z, fa.stride, pi);
-      float q[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++)  // the very transform of k_key1
-        q[r] = __fadd_rn(__fmul_rn(fa.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(fa.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(fa.tf[4 * r + 2], p2), fa.tf[4 * r + 3])));
+      const float q[3] = {fq[3 * i], fq[3 * i + 1], fq[3 * i + 2]};
       const int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], hoff0), g.inv[0])));
       const int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], hoff1), g.inv[1])));
       const int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], hoff2), g.inv[2])));

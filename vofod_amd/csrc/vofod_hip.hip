@@ -1064,7 +1064,8 @@ RefLattice fill_ref_lattice(const GridParams& g)
   const float u = 1.1920929e-7f;  // 2^-23
   const float e1 = 2.0f * (2.0f * cmax) * inv_max * u, e2 = 2.0f * cmax * u * inv_max + dmax * 2.0f * u;
   rl.eps = 4.0f * (e1 + e2) + 1e-4f;
-  rl.on = on && rl.eps < 0.2f && rl.dims[0] > 0 && rl.dims[1] > 0 && rl.dims[2] > 0 && rl.dims[0] <= 2048 && rl.dims[1] <= 2048 && rl.dims[2] <= 1024;
+  // (eps < 0.05: at most ~30 % of the points are fragile, and three words of the frame's side list hold each of them)
+  rl.on = on && rl.eps < 0.05f && rl.dims[0] > 0 && rl.dims[1] > 0 && rl.dims[2] > 0 && rl.dims[0] <= 2048 && rl.dims[1] <= 2048 && rl.dims[2] <= 1024;
   return rl;
 }
 
