@@ -8,5 +8,5 @@ mkdir -p $OUT
 # before python starts - the variable has to come from this shell
 export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 12 --warmup 3 --cpu-baseline-scans 0 --no-profile-pass --host-input-steps 0 > $OUT/p.log 2>&1 || { tail -5 $OUT/p.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 12 --warmup 3 --cpu-baseline-scans 0 --no-profile-pass --host-input-steps 0 --loaded-tail-steps 0 > $OUT/p.log 2>&1 || { tail -5 $OUT/p.log; exit 1; }
 cd $R && python3 tools/timeline.py $OUT/p > $OUT/timeline.txt; head -50 $OUT/timeline.txt
