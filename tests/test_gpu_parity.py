@@ -108,14 +108,24 @@ def test_cluster_tolerance_boundary(oracle, hip):
     np.testing.assert_array_equal(lb, la)
 
 
-def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2):
-    """Step both detectors through the same scans; every step starts from identical maps."""
+def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2, debug=True):
+    """Step both detectors through the same scans; every step starts from identical maps.  debug=False: the production call of
+    a sensor stream (no debug output: the classification tail runs on the device and writes its frontiers to the map itself)."""
     n_det = 0
-    for k, s in enumerate(scans):
-        dr, gr = ref.process_scan(s.scan, s.tf, flags=flags, debug=True)
-        dh, gh = dev.process_scan(s.scan, s.tf, flags=flags, debug=True)
-        assert_scan_debug_equal(gr, gh)
+
+    def step(s, fl):
+        if debug:
+            dr, gr = ref.process_scan(s.scan, s.tf, flags=fl, debug=True)
+            dh, gh = dev.process_scan(s.scan, s.tf, flags=fl, debug=True)
+            assert_scan_debug_equal(gr, gh)
+        else:
+            dr = ref.process_scan(s.scan, s.tf, flags=fl)
+            dh = dev.process_scan(s.scan, s.tf, flags=fl)
         assert_detections_equal(dr, dh)
+        return dr
+
+    for k, s in enumerate(scans):
+        dr = step(s, flags)
         n_det += len(dr)
         np.testing.assert_array_equal(dev.read_map(capi.MAP_VOXELS), ref.read_map(capi.MAP_VOXELS))
         np.testing.assert_array_equal(dev.read_map(capi.MAP_FLAGS), ref.read_map(capi.MAP_FLAGS))
@@ -126,10 +136,7 @@ def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2):
             # tolerance: float-atomic accumulation order
             np.testing.assert_allclose(rb, ra, rtol=2e-5, atol=2e-6)
             nxt = scans[k + 1]
-            dr, gr = ref.process_scan(nxt.scan, nxt.tf, debug=True)
-            dh, gh = dev.process_scan(nxt.scan, nxt.tf, debug=True)
-            assert_scan_debug_equal(gr, gh)
-            assert_detections_equal(dr, dh)
+            step(nxt, capi.SCAN_DEFAULT)
             assert ref.raycast_finish() == dev.raycast_finish() == capi.OK
             ma, mb = ref.read_map(capi.MAP_VOXELS), dev.read_map(capi.MAP_VOXELS)
             fin = np.isfinite(ma)
@@ -146,28 +153,41 @@ def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2):
     return n_det
 
 
+@pytest.mark.parametrize("debug", [True, False])
 @pytest.mark.parametrize("sensor,vs", [("os1-16", 0.5), ("os1-128", 0.5), ("os1-128", 0.25)])
-def test_process_scan_sequence_parity(oracle, hip, sensor, vs):
+def test_process_scan_sequence_parity(oracle, hip, sensor, vs, debug):
     ref, dev = make_pair(oracle, hip, sensor, vs)
     scene = synth.make_scene(11, n_targets=2)
     scans = synth.scan_sequence(scene, sensor, 5, seed0=100)
     for d in (ref, dev):
         synth.seed_ground(d)
-    _run_sequence(ref, dev, scans)
+    _run_sequence(ref, dev, scans, debug=debug)
     assert dev.status().detection_its == ref.status().detection_its
 
 
-def test_process_scan_with_apriori_map_detects(oracle, hip):
-    """config 3 shape: apriori (+inf) background, latches set, classification + flood fill active."""
-    ref, dev = make_pair(oracle, hip, "os1-128", 0.5)
+@pytest.mark.parametrize("debug", [True, False])
+def test_process_scan_with_apriori_map_detects(oracle, hip, debug, vs=0.5):
+    """config 3 shape: apriori (+inf) background, latches set, classification + flood fill active - with the debug output (host
+    tail) and without (round 4: the device tail of a single map-updating scan; the map must equal the oracle's after every scan,
+    frontier voxels of the flood fills included)."""
+    ref, dev = make_pair(oracle, hip, "os1-128", vs)
     scene = synth.make_scene(21, n_targets=3)
-    ap = synth.apriori_points(scene, 0.5)
+    ap = synth.apriori_points(scene, vs)
     for d in (ref, dev):
         d.load_apriori(ap)
     np.testing.assert_array_equal(dev.read_map(), ref.read_map())
     scans = synth.scan_sequence(scene, "os1-128", 4, seed0=300)
-    n_det = _run_sequence(ref, dev, scans, sep_every=2)
+    n_det = _run_sequence(ref, dev, scans, sep_every=2, debug=debug)
     assert n_det > 0  # the floating boxes are found, identically on both sides
+    if not debug and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK") and os.environ.get("VOFOD_DEVICE_TAIL") != "0":
+        lib = dev.lib
+        lib.profile_enable(dev.h, 1)
+        dev.process_scan(scans[0].scan, scans[0].tf)
+        names, ms, calls = (C.c_char * (64 * 96))(), (C.c_double * 96)(), (C.c_uint64 * 96)()
+        nk = lib.profile_read(dev.h, names, ms, calls, 96)
+        lib.profile_enable(dev.h, 0)
+        ran = [names[64 * i : 64 * i + 64].split(b"\0", 1)[0].decode() for i in range(nk)]
+        assert "k_tail_prep" in ran and "k_explore" in ran and "k_tail_finish" in ran and "k_pack" not in ran, ran
 
 
 def test_ingest_apriori_from_file(oracle, hip, tmp_path):

@@ -150,6 +150,16 @@ def main():
                 rb["id"] = (rb["id"].astype(np.int64) + int(ra["id"][0]) - int(rb["id"][0])).astype(rb["id"].dtype)
             assert_detections_equal(ra, rb)
             np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+            # ... and one without debug output: the production call of a sensor stream (device tail; frontiers written by the kernel)
+            s2 = base[-1]
+            rc = ref.process_scan(s2.scan, s2.tf)
+            rd = dev.process_scan(s2.scan, s2.tf)
+            if len(rc) and len(rd):
+                rd = rd.copy()
+                rd["id"] = (rd["id"].astype(np.int64) + int(rc["id"][0]) - int(rd["id"][0])).astype(rd["id"].dtype)
+            assert_detections_equal(rc, rd)
+            np.testing.assert_array_equal(dev.read_map(), ref.read_map())
+            np.testing.assert_array_equal(dev.read_map(capi.MAP_FLAGS), ref.read_map(capi.MAP_FLAGS))
             # the raycast accumulation of that scan (LUT offsets, mask and intensity gate are inputs of this stage only)
             sa = status_of(lambda: ref.raycast_begin(s.scan, s.tf))
             sb = status_of(lambda: dev.raycast_begin(s.scan, s.tf))

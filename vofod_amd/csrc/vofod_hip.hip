@@ -1969,7 +1969,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   ws.finalize_fused = false;
   const bool lite_on = !switch_off("VOFOD_LITE");
   const bool dtail_on = !switch_off("VOFOD_DEVICE_TAIL");
-  ws.dtail = dtail_on && !dbg && n >= 4 && no_update;
+  // (round 4: a single map-updating scan - the reference's own mode - takes the device tail too: no cluster table down, explore
+  // jobs up, results down between the kernels; the flood fills then write their frontiers to the map itself, vofod_nodelet.cpp:1712-1715)
+  // (not under VOFOD_SCAN_AUTO_RAYCAST: that schedule applies the pending raycast update between ++its and the classification,
+  // i.e. between the kernels enqueued here and the tail - the host tail keeps that order)
+  const bool single_update = !no_update && n == 1 && phase == FRAMES_SYNC && !(flags & VOFOD_SCAN_AUTO_RAYCAST);
+  ws.dtail = dtail_on && !dbg && ((n >= 4 && no_update) || single_update);
   ws.lite = !ws.dtail && lite_on && !dbg && n >= 4 && no_update;
   hipStream_t tail_stream_used = h->stream;  // where the device tail's last operation was enqueued
   if (ws.dtail)
@@ -2039,7 +2044,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ep.thr_ground = thr_new;
     ep.frontier_value = static_cast<float>(dp.voxel_map__thresholds__frontiers);
     ep.ray_score = dp.voxel_map__scores__ray;
-    ep.no_update = 1;
+    ep.no_update = no_update ? 1 : 0;
     ep.stack_cap = vc::EX_CELLS;
     // the records (135 KB) go straight into the pinned host slots from the last tail kernel: no copy command on any stream (see k_tail_finish)
     if (ws.far_ran && ws.close_first == 1)
@@ -2231,7 +2236,53 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
         ret = VOFOD_ERR_CAPACITY;
       return ret;
     }
+    if (!no_update && (fb & (vtd::TAIL_FB_DETS | vtd::TAIL_FB_EXPLORE)))
+    {
+      // A map-updating scan whose flood fills have already written their frontiers to the map: the tail cannot be run again.
+      // More detections than the record slots hold (TP_MAXD per frame): everything needed is on the device - the clusters in
+      // canonical order (d_tailc) and their explore results.  (A work list overflow cannot happen for radii the device accepts.)
+      if (fb & vtd::TAIL_FB_EXPLORE)
+      {
+        h->err = "device tail: flood-fill work list overflow";
+        return VOFOD_ERR_DEVICE;
+      }
+      std::vector<vtd::TailCluster> tc(vtd::TP_MAXC);
+      std::vector<vc::ExploreResult> res(vtd::TP_MAXC);
+      HIPCHK(hipMemcpy(tc.data(), ws.d_tailc, sizeof(vtd::TailCluster) * vtd::TP_MAXC, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(res.data(), h->explore.d_results, sizeof(vc::ExploreResult) * vtd::TP_MAXC, hipMemcpyDeviceToHost));  // (frame 0: result slots 0..TP_MAXC-1)
+      size_t total = 0;
+      const float* tf = tfs;
+      for (int c = 0; c < vtd::TP_MAXC; c++)
+      {
+        if (tc[c].job < 0 || tc[c].job >= vtd::TP_MAXC || !res[tc[c].job].floating)
+          continue;
+        vofod_detection det{};
+        const float d[3] = {tf[3] - tc[c].obb_center[0], tf[7] - tc[c].obb_center[1], tf[11] - tc[c].obb_center[2]};
+        const double det_dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        det.id = h->last_detection_id++;
+        det.frame = 0;
+        det.n_points = tc[c].n_members;
+        const float cov = static_cast<float>(std::sqrt(det_dist) * dp.output__position_sigma);
+        for (int q = 0; q < 3; q++)
+          det.covariance[4 * q] = cov;
+        const double u = res[tc[c].job].conf_sum / tc[c].n_members;  // :860-865
+        det.confidence = static_cast<float>(1.0 / std::exp(u));
+        const double vray_res = sp.sensor_vfov / static_cast<double>(sp.sensor_vrays);
+        const double hray_res = 2 * M_PI / static_cast<double>(sp.sensor_hrays);
+        det.detection_probability = std::min(std::atan(1.0 / det_dist) / (vray_res * dp.classification__min_points), 1.0) * std::min(std::atan(1.0 / det_dist) / hray_res, 1.0);
+        for (int a = 0; a < 3; a++)
+          det.position[a] = tc[c].obb_center[a];
+        if (out && total < cap)
+          out[total] = det;
+        total++;
+      }
+      if (n_out_per_frame)
+        n_out_per_frame[0] = static_cast<uint32_t>(total);
+      *n_out = total;
+      return total > cap ? VOFOD_ERR_CAPACITY : ret;
+    }
     // a frame exceeded a capacity of the device tail: the host tail redoes the batch from the full tables
+    // (capacities of k_tail_prep - members, clusters, radius: no flood fill has run yet, also on a map-updating scan)
     ws.dtail = false;
     KLAUNCH(h, k_pack, fgrid(g, (std::max(SPEC_C, SPEC_M) + 255) / 256), dim3(256), g, ws.d_hdrs, ws.d_table, ws.d_cand, ws.va, ws.d_packed);
     HIPCHK(hipMemcpyAsync(ws.h_packed, ws.d_packed, sizeof(PackedFrame) * n, hipMemcpyDeviceToHost, h->stream));
