@@ -134,3 +134,46 @@ def test_far_blobs_at_exactly_the_tolerance_from_close_voxels(oracle, hip):
             hit = np.flatnonzero((np.abs(w["x"] - fx) < 0.01) & (np.abs(w["y"] - fy) < 0.01) & (np.abs(w["z"] - fz) < 0.01))
             assert len(hit) == 1, (d2, f)
             assert (lab[hit[0]] != capi.LABEL_NONE) == (d2 >= 36), (d2, f)
+
+
+def test_tiny_sensor_tiny_workspace(oracle, hip):
+    """a 16-ray sensor: workspaces of 16 voxel slots per frame (the close-first kernel's scratch lists are sized by them; a list that
+    cannot hold its pairs sends the batch to the full clustering).  Four frames of hand-placed returns over a background sheet:
+    pillars standing on it (close), blobs in the air (far), everything compared in the far-only view and as detections."""
+    from vofod_amd.detector import VoFOD, default_params
+
+    W, H, vs = 8, 2, 0.25
+    dets = []
+    for lib in (oracle, hip):
+        sp, dp = default_params(lib)
+        sp.voxel_size = vs
+        sp.oparea_offset[:] = (4.0, 4.0, 0.0)
+        sp.oparea_size[:] = (8.0, 8.0, 8.0)
+        sp.sensor_hrays, sp.sensor_vrays = W, H
+        sp.max_batch_frames = 4
+        dp.classification__min_points = 1
+        dets.append(VoFOD(lib, sp, dp))
+    ref, dev = dets
+    assert dev.map_size == (33, 33, 33)
+    ix, iy = np.meshgrid(np.arange(2, 31), np.arange(2, 31), indexing="ij")
+    sheet = np.stack([(ix.ravel() + 0.5) * vs, (iy.ravel() + 0.5) * vs, np.full(ix.size, 2.5 * vs)], axis=1).astype(np.float32)
+    for d in (ref, dev):
+        d.load_apriori(sheet)  # background in map layer 2
+    rng = np.random.default_rng(7)
+    t = (4.0, 4.0, 7.5)
+    frames = []
+    for f in range(4):
+        cells = []
+        for k in range(3):  # pillars from the sheet upwards: close clusters
+            cx, cy = int(rng.integers(6, 26)), int(rng.integers(6, 26))
+            cells += [(cx, cy, 3 + j) for j in range(int(rng.integers(1, 3)))]
+        for k in range(2 + f % 2):  # blobs 12+ cells above the sheet: far clusters
+            cx, cy, cz = int(rng.integers(6, 26)), int(rng.integers(6, 26)), int(rng.integers(16, 24))
+            cells += [(cx, cy, cz), (cx + 1, cy, cz)]
+        cells = cells[: W * H]
+        pts = [((a + 0.5) * vs, (b + 0.5) * vs, (c + 0.5) * vs) for (a, b, c) in cells]
+        frames.append(_cells_scan(pts, t, w=W, h=H))
+    tf = np.float32([[1, 0, 0, t[0]], [0, 1, 0, t[1]], [0, 0, 1, t[2]]])
+    ga, gb, da = _check_far_view(ref, dev, frames, np.stack([tf] * 4))
+    assert sum(int((g["clusters"]["is_close"] == 0).sum()) for g in ga) >= 6
+    assert sum(int(g["clusters"]["is_close"].sum()) for g in ga) >= 4

@@ -1842,8 +1842,19 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       __syncthreads();
     }
     FR_STAMP(8);
+    if (s_no > hcap)
     {
-      const uint32_t no = min(s_no, hcap);
+      // more open pairs than the scratch list holds (a tiny workspace: the list has five words per voxel slot): nothing may
+      // be dropped - the batch takes the full clustering
+      if (tid == 0)
+      {
+        h.status = CF_RETRY_STATUS;
+        h.V = 0;
+      }
+      return;
+    }
+    {
+      const uint32_t no = s_no;
       for (uint32_t i = tid; i < no; i += FR_THREADS)
       {
         const uint32_t e = hits[i];
