@@ -47,6 +47,7 @@ struct FrameHdr
   uint32_t need_words;  // bitmap words the lattice needs (reported even when it exceeds the workspace)
   uint32_t n_bricks;    // occupied 4x4x4 bricks (brick-level clustering)
   uint32_t n_undecided; // voxels whose own map row is empty: k_closefar_sweep tests their whole stencil
+  uint32_t n_far;       // (close-first on the general path) voxels the sweep found no background voxel for
   uint32_t far_only;         // k_frame_lds clustered close first: the cluster table holds the far clusters only, no labels were written
   uint32_t n_cand_clusters;  // ... and begins with this many candidate clusters in the canonical order, their members sorted (k_tail_far)
 };

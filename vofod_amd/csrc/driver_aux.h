@@ -1041,7 +1041,12 @@ int vofod_process_scan(vofod_handle* h, const vofod_scan* scan, const float tf[1
   if (const int b = busy_check(h, true, !(flags & VOFOD_SCAN_NO_MAP_UPDATE)); b != VOFOD_OK)
     return b;
   *n_out = 0;
-  return process_frames(h, h->ws, FRAMES_SYNC, scan, tf, 1, flags, out, cap, nullptr, n_out, dbg);
+  int r = process_frames(h, h->ws, FRAMES_SYNC, scan, tf, 1, flags, out, cap, nullptr, n_out, dbg);
+  // (a cold map: more far voxels than the close-first path of a single scan takes - nothing of the scan was applied; once more,
+  // through the full clustering)
+  if (r == CCL_RETRY_STATUS)
+    r = process_frames(h, h->ws, FRAMES_SYNC, scan, tf, 1, flags, out, cap, nullptr, n_out, dbg);
+  return r;
 }
 
 int vofod_process_batch(vofod_handle* h, const vofod_scan* scans, const float* tfs, size_t n, vofod_detection* out, size_t cap, uint32_t* n_out_per_frame, size_t* n_out,

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
   int ox = 0, oy = 0, oz = 0;
   bool undecided = false;
   if (active)
-    root = labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v];
+    root = labels_all ? labels_all[static_cast<size_t>(FRAME) * g.vox_cap + v] : v;  // (no labels: every voxel for itself - kernels_far.h)
   // the cluster's "already close" flag is read once per run of equal roots and handed to the run's lanes
   uint32_t flag = 0;
   {
@@ -636,7 +636,8 @@ __global__ __launch_bounds__(256) void k_closefar(const GridParams g, const MapG
 // The stencil sweep of the voxels k_closefar could not decide from their own row: 16 lanes per voxel over the nearest-first
 // rows, as many workgroups as the list needs (a kernel of its own so that a single frame gets thousands of waves).
 __global__ __launch_bounds__(256) void k_closefar_sweep(const GridParams g, const MapGeom mg, const CloseParams cp, const CloseRow* __restrict__ rows, const FrameHdr* hdrs,
-                                                        const unsigned long long* __restrict__ mapbits, VoxelArrays va_all, const CandMember* __restrict__ undecided_all)
+                                                        const unsigned long long* __restrict__ mapbits, VoxelArrays va_all, const CandMember* __restrict__ undecided_all,
+                                                        uint32_t* __restrict__ far_list = nullptr, FrameHdr* hdrs_w = nullptr, uint32_t far_cap = 0)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
@@ -680,6 +681,13 @@ __global__ __launch_bounds__(256) void k_closefar_sweep(const GridParams g, cons
   }
   if (found && sub == 0)
     __hip_atomic_store(&va.cclose[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (close-first on the general path, kernels_far.h: with every voxel as its own cluster, a voxel nothing was found for is FAR)
+  if (far_list && live && !found && sub == 0)
+  {
+    const uint32_t pos = atomicAdd(&hdrs_w[FRAME].n_far, 1u);
+    if (pos < far_cap)
+      far_list[pos] = undecided_all[static_cast<size_t>(FRAME) * g.vox_cap + u].v;
+  }
 }
 
 // K10 + cluster table + candidate members.

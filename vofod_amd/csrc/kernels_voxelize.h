@@ -147,6 +147,7 @@ __global__ void k_init_hdr(FrameHdr* hdrs, uint32_t* counts2)
     h.need_words = 0;
     h.n_bricks = 0;
     h.n_undecided = 0;
+    h.n_far = 0;
     h.far_only = 0;
     h.n_cand_clusters = 0;
   }

@@ -28,6 +28,7 @@
 #include "kernels_raycast.h"
 #include "kernels_slab.h"
 #include "kernels_tail.h"
+#include "kernels_far.h"
 #include "kernels_voxelize.h"
 
 using namespace vk;
@@ -1939,15 +1940,44 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   if (h->cf_off && (h->n_bg_voxels > h->cf_off_bg + h->cf_off_bg / 4 + 1000 || h->n_bg_voxels < h->cf_off_bg))
     h->cf_off = false;  // the map has changed a lot since: try the close-first kernel again
   ws.close_first = (close_first_on && use_dilated && !h->cf_off) ? (dbg ? (dbg_far_only ? 2 : 0) : 1) : 0;
+  const uint32_t gv = (ws.vox_cap + 255u) / 256u;
+  // A single map-updating scan without debug output (the reference's own mode) clusters close first on the general path
+  // (kernels_far.h): close bits from hasCloseTo's stencil with every voxel as its own cluster, then edges and unions around the
+  // far voxels only - instead of the six brick kernels over the whole frame.
+  const bool dtail_wanted = !switch_off("VOFOD_DEVICE_TAIL");
+  bool far_single = close_first_on && !h->cf_off && !dbg && !no_update && n == 1 && phase == FRAMES_SYNC && !(flags & VOFOD_SCAN_AUTO_RAYCAST) && dtail_wanted && !frame_path && !keep_dirty;
+  if (far_single)
+  {
+    vofod_handle::ClusterTables* ct = nullptr;
+    r = cluster_tables(h, g, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), &ct);
+    if (r != VOFOD_OK)
+      return r;
+    far_single = ct->n_rows > 0 && ws.vox_cap >= FAR_MAX;
+    if (far_single)
+    {
+      uint32_t* far_list = ws.d_labels;  // (labels are not written on this path)
+      KLAUNCH(h, k_closefar, fgrid(g, gv), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, static_cast<const uint32_t*>(nullptr), static_cast<const unsigned long long*>(nullptr), ws.d_cand,
+              ws.d_hdrs);
+      KLAUNCH(h, k_closefar_sweep, fgrid(g, (ws.vox_cap * 16u + 255u) / 256u), dim3(256), g, h->mg, cpar, h->d_crows, ws.d_hdrs, h->d_mapbits, ws.va, ws.d_cand, far_list, ws.d_hdrs, ws.vox_cap);
+      const uint32_t items = FAR_MAX * 2u * static_cast<uint32_t>(ct->n_rows);
+      KLAUNCH(h, k_far_edges, dim3((items + 255u) / 256u), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, far_list);
+      KLAUNCH(h, k_far_final, dim3(1), dim3(1024), g, ws.d_hdrs, ws.va, far_list, up, ws.d_table, ws.d_cand);
+      KLAUNCH(h, k_finalize_far, dim3(gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, h->d_map, h->d_flags, ws.d_bitmaps);
+      ws.closefar_fused = true;
+      ws.finalize_fused = true;
+    }
+  }
+  if (!far_single)
+  {
   r = launch_cluster(h, ws, g, n, static_cast<float>(dp.ground_points_max_distance), map_cmax(h), no_update && n >= 4, use_dilated ? h->d_mapclose : nullptr,
                      (keep_dirty && no_update) ? &up : nullptr);
   if (r != VOFOD_OK)
     return r;
+  }
   if (dbg)
     HIPCHK(hipEventRecord(ev[2], h->stream));
 
   // ---- K8/K9 findCloseFarClusters :703-750 (tables and images were prepared before the chain was enqueued)
-  const uint32_t gv = (ws.vox_cap + 255u) / 256u;
   if (!ws.closefar_fused)
   {
     // few frames: the undecided voxels go through a list to a sweep kernel with 16 lanes per voxel (ws.d_cand is free until
