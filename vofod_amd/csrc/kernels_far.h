@@ -216,8 +216,11 @@ __global__ __launch_bounds__(1024) void k_far_final(const GridParams g, FrameHdr
 }
 
 // updateVoxel (vofod_nodelet.cpp:777-797) voxel by voxel; the frame's occupancy bitmap is left all-zero for the next call
+// `mapbits` (nullable): the map's occupancy image (bit = m > thr_new, k_mapbits) and its partial nVoxelsOver counters are patched
+// where this scan's update flips a voxel's bit - a sensor stream then never rebuilds the image (k_mapbits: a 78 MB sweep, 21 us per
+// scan) between two scans.
 __global__ __launch_bounds__(256) void k_finalize_far(const GridParams g, const MapGeom mg, const UpdateParams up, FrameHdr* hdrs, VoxelArrays va, float* __restrict__ vmap, float* __restrict__ vflags,
-                                                      unsigned long long* __restrict__ bitmaps)
+                                                      unsigned long long* __restrict__ bitmaps, unsigned long long* __restrict__ mapbits, unsigned long long* __restrict__ bgcount, float thr_new)
 {
   FrameHdr& h = hdrs[0];
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -241,8 +244,24 @@ __global__ __launch_bounds__(256) void k_finalize_far(const GridParams g, const 
     const float w = __uint_as_float((127u - c) << 23);  // 1.0f / float(1lu << c), exact
     const float score = close ? up.score_point : up.score_unknown;
     const float m = vmap[li];
-    vmap[li] = __fadd_rn(__fmul_rn(w, m), __fmul_rn(__fsub_rn(1.0f, w), score));
+    const float m2 = __fadd_rn(__fmul_rn(w, m), __fmul_rn(__fsub_rn(1.0f, w), score));
+    vmap[li] = m2;
     vflags[li] = close ? 2.0f : 3.0f;  // m_vflags_point / m_vflags_unknown (:2336-2337)
+    if (mapbits && (m > thr_new) != (m2 > thr_new))
+    {
+      // (one voxel of the aligned lattice per map cell: this thread is the cell's only writer)
+      const unsigned long long bit = 1ull << (li & 63);
+      if (m2 > thr_new)
+      {
+        atomicOr(&mapbits[li >> 6], bit);
+        atomicAdd(&bgcount[(li & (MB_SLOTS - 1)) * 8], 1ull);
+      }
+      else
+      {
+        atomicAnd(&mapbits[li >> 6], ~bit);
+        atomicAdd(&bgcount[(li & (MB_SLOTS - 1)) * 8], ~0ull);  // - 1 (the host sums the partial counters modulo 2^64)
+      }
+    }
   }
 }
 

@@ -305,6 +305,7 @@ struct Workspace
   PackedLite* d_lite = nullptr;
   PackedLite* h_lite = nullptr;  // pinned
   bool lite = false;  // the batch in this workspace was read back through the lite slots (no debug output asked for)
+  bool mapbits_patched = false;  // k_finalize_far kept the map's occupancy image and counters up to date with this scan's update
   bool far_ran = false;  // launch_cluster ran k_frame_lds_far: the cluster table and the member list are in the order k_tail_far reads
   int close_first = 0;  // k_frame_lds: 1 = cluster the far voxels only (read-only batches), 2 = the same with labels for the far-only debug view
   bool dtail = false;  // ... or its classification tail ran on the device (kernels_tail.h): only detection records come back
@@ -507,6 +508,7 @@ struct vofod_handle
   // (nVoxelsOver well above the count at the overflow) or was reset.
   bool cf_off = false;
   uint64_t cf_off_bg = 0;
+  bool bgcount_stale = false;  // k_finalize_far patched the nVoxelsOver counters on the device: n_bg_voxels is older than they are
   bool lds_ccl_off = false;  // a frame of the batch just collected overflowed the LDS kernels: the NEXT launch (its re-run) takes the global-memory kernels, then the flag drops
   std::mutex mtx;
   vofod_static_params sp{};
@@ -1473,10 +1475,29 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
 }
 
 // nVoxelsOver + occupancy image of the map, cached while the map and the threshold are unchanged
+// nVoxelsOver (:715) from the patched counters of a sensor stream - fetched only when it can still change something (the
+// background latch not yet set, debug output): a round trip of ~10 us per scan otherwise
+int refresh_bgcount(vofod_handle* h)
+{
+  if (!h->bgcount_stale)
+    return VOFOD_OK;
+  h->bgcount_stale = false;
+  if (!h->mapbits_valid)
+    return VOFOD_OK;  // (the image is about to be rebuilt, the count with it)
+  HIPCHK(hipMemcpy(h->h_bgcount, h->d_bgcount, sizeof(unsigned long long) * 8 * MB_SLOTS, hipMemcpyDeviceToHost));
+  uint64_t t = 0;
+  for (int i = 0; i < MB_SLOTS; i++)
+    t += h->h_bgcount[8 * i];
+  h->n_bg_voxels = t;
+  h->bgcount_fresh = false;
+  return VOFOD_OK;
+}
+
 int ensure_mapbits(vofod_handle* h, float thr)
 {
   if (h->mapbits_valid && h->mapbits_thr == thr)
     return VOFOD_OK;
+  h->bgcount_stale = false;  // (rebuilt below: image and count)
   // the image is shared with every batch in flight (their chains read it from streams of their own): let them finish first
   for (int t = 0; t < vofod_handle::MAX_INFLIGHT; t++)
     if (h->slot(t)->pending && h->slot(t)->ev_done)
@@ -1865,6 +1886,11 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   r = ensure_mapbits(h, thr_new);
   if (r != VOFOD_OK)
     return r;
+  // (a sensor stream's patched nVoxelsOver counters - k_finalize_far of the PREVIOUS scan - are fetched here, before this scan's
+  // own update is enqueued, and only while the count can still change something: the background latch, the debug output)
+  if (!h->background_pts_sufficient || dbg)
+    if (const int rb = refresh_bgcount(h); rb != VOFOD_OK)
+      return rb;
   if (!h->closetab.valid || h->closetab.max_dist != static_cast<float>(dp.ground_points_max_distance))
   {
     std::vector<CloseRow> crows;
@@ -1962,7 +1988,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       const uint32_t items = FAR_MAX * 2u * static_cast<uint32_t>(ct->n_rows);
       KLAUNCH(h, k_far_edges, dim3((items + 255u) / 256u), dim3(256), g, ct->cp, ct->d_rows, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, far_list);
       KLAUNCH(h, k_far_final, dim3(1), dim3(1024), g, ws.d_hdrs, ws.va, far_list, up, ws.d_table, ws.d_cand);
-      KLAUNCH(h, k_finalize_far, dim3(gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, h->d_map, h->d_flags, ws.d_bitmaps);
+      // The occupancy image is patched where the update flips a bit (valid while one voxel of the scan falls into one map cell -
+      // the aligned lattice - and the flood fills' frontier value is no background value: their writes then flip nothing).
+      ws.mapbits_patched = g.align && static_cast<float>(dp.voxel_map__thresholds__frontiers) <= thr_new;
+      KLAUNCH(h, k_finalize_far, dim3(gv), dim3(256), g, h->mg, up, ws.d_hdrs, ws.va, h->d_map, h->d_flags, ws.d_bitmaps, ws.mapbits_patched ? h->d_mapbits : nullptr, h->d_bgcount, thr_new);
       ws.closefar_fused = true;
       ws.finalize_fused = true;
     }
@@ -2156,7 +2185,22 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       return CCL_RETRY_STATUS;
     }
   if (!no_update)
-    h->mapbits_valid = false;
+  {
+    bool keep = false;
+    if (ws.mapbits_patched)
+    {
+      // (the image was patched by k_finalize_far - unless the scan has to run again or left the map: then it is rebuilt)
+      keep = ws.h_packed[0].hdr.status == VOFOD_OK && h->mapbits_valid;
+      ws.mapbits_patched = false;
+    }
+    if (keep)
+    {
+      h->bgcount_stale = true;  // (the counters on the device are newer than the host's sum: fetched when somebody needs it)
+      h->mapbits_gen++;         // (the dilated image of the batches is of an older state)
+    }
+    else
+      h->mapbits_valid = false;
+  }
 
   if (h->bgcount_fresh)
   {
@@ -2168,6 +2212,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     h->n_bg_voxels = t;
     h->bgcount_fresh = false;
   }
+  // (n_bg_voxels is the count findCloseFarClusters saw, i.e. of the map BEFORE this call's update; counters patched by this very
+  // call - bgcount_stale set above - belong to the next one and are not fetched here)
   if (h->n_bg_voxels > h->background_min_sufficient_pts)  // :716-721
     h->background_pts_sufficient = true;
   for (uint32_t f = 0; f < n; f++)
