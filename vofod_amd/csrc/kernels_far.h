@@ -104,10 +104,31 @@ __global__ __launch_bounds__(256) void k_far_edges(const GridParams g, const Clu
     __hip_atomic_store(&va.csize[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// record of a surviving component (sizes and boxes accumulated in its root's slots)
+__device__ __forceinline__ ClusterRec far_record(const GridParams& g, const UpdateParams& up, const VoxelArrays& va, uint32_t root)
+{
+  ClusterRec rec;
+  rec.root = root;
+  rec.size = __hip_atomic_load(&va.csize[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int ext_ok = 1;
+  for (int a = 0; a < 3; a++)
+  {
+    rec.imin[a] = __hip_atomic_load(&va.cbox[6 * root + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rec.imax[a] = __hip_atomic_load(&va.cbox[6 * root + 3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ext_ok &= (static_cast<float>(rec.imax[a] - rec.imin[a]) * g.leaf[a] <= up.cand_max_extent);
+  }
+  rec.close = 0u;
+  rec.cand = (static_cast<int>(rec.size) >= up.min_points && ext_ok) ? 1u : 0u;
+  return rec;
+}
+
 __global__ __launch_bounds__(1024) void k_far_final(const GridParams g, FrameHdr* hdrs, VoxelArrays va, const uint32_t* __restrict__ far_list, const UpdateParams up, ClusterRec* __restrict__ table,
                                                     CandMember* __restrict__ cands)
 {
-  __shared__ uint32_t s_C, s_nc;
+  __shared__ uint32_t s_C, s_nc, s_ncc;
+  __shared__ ClusterRec s_rec[TAIL_MAXC];
+  __shared__ uint32_t s_oroot[TAIL_MAXC];
+  __shared__ unsigned long long s_key[TAIL_MAXM];
   FrameHdr& h = hdrs[0];
   const uint32_t n_far = h.n_far;
   const int tid = threadIdx.x;
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_far_final(const GridParams g, FrameHdr
     return;
   }
   if (tid == 0)
-    s_C = s_nc = 0;
+    s_C = s_nc = s_ncc = 0;
   constexpr int PT = FAR_MAX / 1024;
   uint32_t vv[PT], rr[PT];
   // 1: roots; a tainted voxel taints its root
@@ -166,29 +187,52 @@ __global__ __launch_bounds__(1024) void k_far_final(const GridParams g, FrameHdr
   }
   __threadfence();
   __syncthreads();
-  // 3: records of the surviving components (the root is the smallest member: the canonical label); candidates as k_finalize
+  // 3: records of the surviving components (the root is the smallest member: the canonical label); candidates as k_finalize.
+  //    The candidates go to the head of the table in the canonical order (size descending, root ascending: counted among
+  //    the <= TAIL_MAXC staged ones) and their members follow cluster by cluster with ascending rank (counted among <= TAIL_MAXM
+  //    staged keys): what k_tail_far reads without sorting, as k_frame_lds_far leaves it.  Beyond those capacities the lists
+  //    stay unordered: the tail raises its fallback flags on the counts.
 #pragma unroll
   for (int q = 0; q < PT; q++)
   {
     if (vv[q] == 0xffffffffu || ((dead >> q) & 1u) || rr[q] != vv[q])
       continue;
     const uint32_t root = vv[q];
-    const uint32_t size = __hip_atomic_load(&va.csize[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ClusterRec rec;
-    rec.root = root;
-    rec.size = size;
-    int ext_ok = 1;
-    for (int a = 0; a < 3; a++)
+    const ClusterRec rec = far_record(g, up, va, root);
+    if (!rec.cand)
     {
-      rec.imin[a] = __hip_atomic_load(&va.cbox[6 * root + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      rec.imax[a] = __hip_atomic_load(&va.cbox[6 * root + 3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ext_ok &= (static_cast<float>(rec.imax[a] - rec.imin[a]) * g.leaf[a] <= up.cand_max_extent);
+      va.bb[root] = 0u;  // (the brick codes of this array serve the brick kernels only: free on this path)
+      continue;
     }
-    rec.close = 0u;
-    const bool cand = static_cast<int>(size) >= up.min_points && ext_ok;
-    rec.cand = cand ? 1u : 0u;
-    va.bb[root] = cand ? 1u : 0u;  // (the brick codes of this array serve the brick kernels only: free on this path)
-    table[atomicAdd(&s_C, 1u)] = rec;
+    const uint32_t slot = atomicAdd(&s_ncc, 1u);
+    if (slot < static_cast<uint32_t>(TAIL_MAXC))
+      s_rec[slot] = rec;
+    else
+    {
+      table[slot] = rec;
+      va.bb[root] = 0x7fffffffu;
+    }
+  }
+  __syncthreads();
+  const uint32_t ncc = s_ncc, n_staged = min(ncc, static_cast<uint32_t>(TAIL_MAXC));
+  if (tid < static_cast<int>(n_staged))
+  {
+    const ClusterRec me = s_rec[tid];
+    uint32_t ord = 0;
+    for (uint32_t u = 0; u < n_staged; u++)
+      ord += (s_rec[u].size > me.size || (s_rec[u].size == me.size && s_rec[u].root < me.root)) ? 1u : 0u;
+    table[ord] = me;
+    s_oroot[ord] = me.root;
+    va.bb[me.root] = ord + 1u;
+  }
+#pragma unroll
+  for (int q = 0; q < PT; q++)
+  {
+    if (vv[q] == 0xffffffffu || ((dead >> q) & 1u) || rr[q] != vv[q])
+      continue;
+    const ClusterRec rec = far_record(g, up, va, vv[q]);
+    if (!rec.cand)
+      table[ncc + atomicAdd(&s_C, 1u)] = rec;
   }
   __threadfence();
   __syncthreads();
@@ -198,19 +242,46 @@ __global__ __launch_bounds__(1024) void k_far_final(const GridParams g, FrameHdr
   {
     if (vv[q] == 0xffffffffu || ((dead >> q) & 1u))
       continue;
-    if (__hip_atomic_load(&va.bb[rr[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    const uint32_t o = __hip_atomic_load(&va.bb[rr[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o)
     {
-      CandMember cm;
-      cm.root = rr[q];
-      cm.v = vv[q];
-      cands[atomicAdd(&s_nc, 1u)] = cm;
+      const uint32_t slot = atomicAdd(&s_nc, 1u);
+      if (slot < static_cast<uint32_t>(TAIL_MAXM))
+        s_key[slot] = (static_cast<unsigned long long>(o - 1u) << 32) | vv[q];
+      else
+      {
+        CandMember cm;
+        cm.root = rr[q];
+        cm.v = vv[q];
+        cands[slot] = cm;
+      }
     }
   }
   __syncthreads();
+  const uint32_t n_cand = s_nc;
+  if (tid < static_cast<int>(min(n_cand, static_cast<uint32_t>(TAIL_MAXM))))
+  {
+    const unsigned long long me = s_key[tid];
+    const uint32_t o = static_cast<uint32_t>(me >> 32);
+    CandMember cm;
+    cm.v = static_cast<uint32_t>(me);
+    uint32_t pos = tid;
+    if (n_cand <= static_cast<uint32_t>(TAIL_MAXM) && ncc <= static_cast<uint32_t>(TAIL_MAXC))
+    {
+      pos = 0;
+      for (uint32_t u = 0; u < n_cand; u++)
+        pos += s_key[u] < me ? 1u : 0u;
+      cm.root = s_oroot[o];
+    }
+    else
+      cm.root = uf_find<0>(va.parent, cm.v);
+    cands[pos] = cm;
+  }
   if (tid == 0)
   {
-    h.C = s_C;
-    h.n_cand = s_nc;
+    h.C = ncc + s_C;
+    h.n_cand = n_cand;
+    h.n_cand_clusters = ncc;
     h.far_only = 1u;
   }
 }

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64) void k_tail_far(const GridParams g, const Frame
                                                 const CandMember* __restrict__ cand_all, VoxelArrays va_all, const MapGeom mg, const TailParams tp, const vc::ExploreParams ep, vc::ExploreJob* __restrict__ jobs,
                                                 int* __restrict__ members_out, float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all,
                                                 uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all,
-                                                vc::ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all, FrameDets* __restrict__ dets, FrameDets* __restrict__ hout)
+                                                vc::ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all, FrameDets* __restrict__ dets, FrameDets* __restrict__ hout,
+                                                TailCluster* __restrict__ tailc)
 {
   __shared__ uint8_t s_float[TP_MAXC];
   __shared__ uint8_t s_walk[6 * 32];
@@ -395,6 +396,15 @@ __global__ __launch_bounds__(64) void k_tail_far(const GridParams g, const Frame
     job.result_slot = slot;
     jobs[slot] = job;
     tc.job = static_cast<int32_t>(slot);
+  }
+  if (tailc)  // (a map-updating scan: the host rebuilds the detections from these when the record slots overflow)
+  {
+    if (!live)
+    {
+      tc = TailCluster{};
+      tc.job = -1;
+    }
+    tailc[f * TP_MAXC + lane] = tc;
   }
   uint32_t fb_all = fallback;
 #pragma unroll

@@ -351,6 +351,33 @@ __global__ __launch_bounds__(256) void k_setbits(const FrameArgs* args, const Gr
 // ---- exclusive prefix sum of the bitmap's word popcounts (3 phases) ------------------------
 constexpr int SCAN_WPT = 4;                    // words per thread
 constexpr int SCAN_WPB = 256 * SCAN_WPT;       // words per block
+constexpr uint32_t EMIT_SPLIT = 4;             // workgroups of k_emit per block of the lattice (small batches)
+
+// position of the u-th (0-based) set bit of w; u < popcount(w)
+__device__ __forceinline__ int nth_set_bit(unsigned long long w, uint32_t u)
+{
+  int pos = 0;
+  uint32_t x = static_cast<uint32_t>(w);
+  uint32_t c = __popc(x);
+  if (u >= c)
+  {
+    u -= c;
+    x = static_cast<uint32_t>(w >> 32);
+    pos = 32;
+  }
+#pragma unroll
+  for (int width = 16; width >= 1; width >>= 1)
+  {
+    c = __popc(x & ((1u << width) - 1u));
+    if (u >= c)
+    {
+      u -= c;
+      x >>= width;
+      pos += width;
+    }
+  }
+  return pos;
+}
 
 // exclusive scan of one value per thread over a 256-thread block; returns the block total via *total
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds4, uint32_t* total)
@@ -537,12 +564,16 @@ __device__ __forceinline__ void brick_append(FrameHdr& h, const BrickArrays& ba,
 // thread then produces output slots t, t+256, ... (locating the owning word by binary search), so the
 // voxel records leave the CU as coalesced 16-byte-per-lane stores regardless of how the set bits cluster.
 __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs, const unsigned long long* bitmaps, const uint32_t* blocksums,
-                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all, const BrickParams bp, BrickArrays ba_all, int brick_on, uint32_t init_count)
+                                              uint32_t nblk_cap, uint32_t* wprefix_all, VoxelArrays va_all, const BrickParams bp, BrickArrays ba_all, int brick_on, uint32_t init_count, uint32_t split)
 {
   uint32_t FRAME, BX, GX;
   if (!frame_block(g, FRAME, BX, GX))
     return;
   (void)GX;
+  // `split` workgroups share a block of the lattice: each scans the block's words (cheap) and emits its share of the
+  // block's voxels - a scan's ground sheet sits in a handful of blocks, whose emission loops set the kernel's time
+  const uint32_t SUB = BX % split;
+  BX /= split;
   FrameHdr& h = hdrs[FRAME];
   if (BX * SCAN_WPB >= h.n_words || h.V == 0)
     return;
@@ -564,7 +595,7 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
     const uint32_t mine = bs[BX], next = (BX + 1 < nblk) ? bs[BX + 1] : h.V;
     if (next == mine)
     {
-      if (!g.sparse_prefix)
+      if (!g.sparse_prefix && SUB == 0)
 #pragma unroll
         for (int k = 0; k < SCAN_WPT; k++)
           if (w0 + k < h.n_words)
@@ -587,6 +618,7 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
   s_start[threadIdx.x] = excl;
   if (threadIdx.x == 0)
     s_start[256] = total;
+  if (SUB == 0)
   {
     uint32_t run = base + excl;
 #pragma unroll
@@ -599,12 +631,18 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
   }
   __syncthreads();
   const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
-  const uint32_t total_round = (total + 63u) & ~63u;  // whole waves stay in the loop (brick_append shuffles)
-  for (uint32_t t = threadIdx.x; t < total_round; t += 256)
+  // this workgroup's share of the block's voxels: [t_lo, t_hi), shares are whole multiples of 256 slots
+  const uint32_t share = (((total + split - 1u) / split) + 255u) & ~255u;
+  const uint32_t t_lo = SUB * share;
+  if (t_lo >= total)
+    return;
+  const uint32_t t_hi = min(total, t_lo + share);
+  const uint32_t t_round = t_lo + ((t_hi - t_lo + 63u) & ~63u);  // whole waves stay in the loop (brick_append shuffles)
+  for (uint32_t t = t_lo + threadIdx.x; t < t_round; t += 256)
   {
     bool first = false;
     uint32_t brick = 0;
-    if (t < total)
+    if (t < t_hi)
     {
       // owner thread j: s_start[j] <= t < s_start[j+1]
       int lo = 0, hi = 256;
@@ -626,9 +664,7 @@ __global__ __launch_bounds__(256) void k_emit(const GridParams g, FrameHdr* hdrs
         w = s_words[++wi];
         pc = __popcll(w);
       }
-      for (uint32_t q = 0; q < u; q++)
-        w &= w - 1;
-      const int b = __ffsll(static_cast<long long>(w)) - 1;
+      const int b = nth_set_bit(w, u);
       const uint32_t key = (wbase + wi) * 64u + b;
       const uint32_t rank = base + t;
       const int k2 = key / dxy;

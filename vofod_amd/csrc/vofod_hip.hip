@@ -1041,6 +1041,7 @@ int stage_cloud(vofod_handle* h, Workspace& ws, uint32_t f, const void* x, const
 
 // 1-D grid of a per-frame kernel: n_frames x gx blocks (see frame_block in kernels_voxelize.h)
 inline dim3 fgrid(const GridParams& g, uint32_t gx) { return dim3(g.n_frames * gx); }
+inline uint32_t emit_split(uint32_t n_frames) { return n_frames <= 16 ? EMIT_SPLIT : 1u; }
 
 // Reference lattice of the single-pass input (kernels_frame.h, k_key1): what voxel_grid_weighted.cpp:72-106 yields for a cloud
 // whose minimum is the operation area's corner, and the band around cell boundaries inside which the frame's own offset may
@@ -1209,7 +1210,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
       const uint32_t slab_g = n <= 32 ? n_slabs : std::max(1u, std::min(n_slabs, 512u / n));
       KLAUNCH(h, k_slab, fgrid(g, slab_g), dim3(SLAB_THREADS), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
       KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-      KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit);
+      KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap * emit_split(n)), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, 0, 1u | lean_bit, emit_split(n));
     }
     // after k_slab_emit only the extras beyond its LDS staging area are left (none on ordinary scans)
     KLAUNCH(h, k_count_extras, fgrid(g, (slab_emit_on && n >= 128) ? 4 : 24), dim3(256), g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.d_bitmaps, ws.d_wprefix, ws.va);
@@ -1222,7 +1223,7 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, lean_bit);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap * emit_split(n)), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, lean_bit, emit_split(n));
   KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
@@ -1240,7 +1241,7 @@ int launch_voxelize_rest(vofod_handle* h, Workspace& ws, const GridParams& g, ui
   KLAUNCH(h, k_setbits, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps);
   KLAUNCH(h, k_scan_a, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap);
   KLAUNCH(h, k_scan_b, dim3(n), dim3(1024), g, ws.d_hdrs, ws.d_blocksums, ws.nblk_cap);
-  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, 0u);
+  KLAUNCH(h, k_emit, fgrid(g, ws.nblk_cap * emit_split(n)), dim3(256), g, ws.d_hdrs, ws.d_bitmaps, ws.d_blocksums, ws.nblk_cap, ws.d_wprefix, ws.va, bpv, ws.ba, bricks ? 1 : 0, 0u, emit_split(n));
   KLAUNCH(h, k_count, fgrid(g, gx), dim3(256), ws.d_args, g, ws.d_hdrs, ws.d_bitmaps, ws.d_wprefix, ws.va, want_ptrank ? ws.d_ptrank : nullptr, ws.pt_cap);
   HIPCHK(hipGetLastError());
   return VOFOD_OK;
@@ -2106,10 +2107,10 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ep.no_update = no_update ? 1 : 0;
     ep.stack_cap = vc::EX_CELLS;
     // the records (135 KB) go straight into the pinned host slots from the last tail kernel: no copy command on any stream (see k_tail_finish)
-    if (ws.far_ran && ws.close_first == 1)
-      // close-first frames: ordered lists from the frame kernel, the whole tail in one kernel of one wave per frame
+    if ((ws.far_ran && ws.close_first == 1) || far_single)
+      // close-first frames: ordered lists from the frame kernel (or k_far_final), the whole tail in one kernel of one wave per frame
       KLAUNCH(h, vtd::k_tail_far, dim3(n), dim3(64), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, ep, eb.d_jobs, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
-              eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited, ws.d_dets, ws.h_dets_dev);
+              eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited, ws.d_dets, ws.h_dets_dev, far_single ? ws.d_tailc : static_cast<vtd::TailCluster*>(nullptr));
     else
     {
       KLAUNCH(h, vtd::k_tail_prep, dim3(n), dim3(vtd::TP_THREADS), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, ws.d_tailc,
