@@ -192,7 +192,11 @@ int counted_tail(vofod_handle* h, Workspace& ws, uint32_t V, uint32_t P, const u
 int voxelize_cloud(vofod_handle* h, Workspace& ws, const vofod_cloud_view* in, GridParams& g, const float leaf[3], bool align, const float* align_center, FrameHdr& hdr)
 {
   const uint32_t n = static_cast<uint32_t>(in->n);
-  if (hipError_t e = ws.ensure(1, std::max(n, 1u), std::max(n, 1u), std::max(ws.words_cap, 1u << 16)); e != hipSuccess)
+  // Growth with headroom: a workspace grows by releasing and allocating its three dozen arrays (2.6 ms), and the cloud of
+  // updateSeparatedBGClusters - the map's background voxels - gains a few thousand points from one call to the next while the map
+  // warms: sized to the point, EVERY call of the role paid that (VOFOD_TRACE: 2.7 of the role's 2.9 ms).
+  const uint32_t want = n > ws.pt_cap ? n + n / 2 + 4096u : std::max(n, 1u);
+  if (hipError_t e = ws.ensure(1, want, want, std::max(ws.words_cap, 1u << 16)); e != hipSuccess)
   {
     h->err = std::string("workspace allocation: ") + hipGetErrorString(e);
     return VOFOD_ERR_DEVICE;
@@ -214,7 +218,7 @@ int voxelize_cloud(vofod_handle* h, Workspace& ws, const vofod_cloud_view* in, G
         hdr.n_in ? static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>((hdr.div_b[0] + 3) / 4) * ((hdr.div_b[1] + 3) / 4) * ((hdr.div_b[2] + 3) / 4), 1u << 28)) : 0u;
     if ((hdr.status == VOFOD_ERR_CAPACITY || (hdr.status == VOFOD_OK && need_bricks > ws.bricks_cap)) && attempt == 0)
     {
-      if (hipError_t e = ws.ensure(1, n, n, hdr.need_words + 64, need_bricks); e != hipSuccess)
+      if (hipError_t e = ws.ensure(1, n, n, hdr.need_words + hdr.need_words / 4 + 64, need_bricks + need_bricks / 4); e != hipSuccess)
       {
         h->err = std::string("workspace allocation: ") + hipGetErrorString(e);
         return VOFOD_ERR_DEVICE;
@@ -251,6 +255,9 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
   h->sep_pending = false;
   h->sep_start_its = h->detection_its;
   vr::SepState& s = h->sep;
+  static const bool trace = std::getenv("VOFOD_TRACE") != nullptr;
+  const auto t0 = clk::now();
+  double tr[5] = {0, 0, 0, 0, 0};
   const float thr_new = static_cast<float>(dp.voxel_map__thresholds__new_obstacles);
   const float thr_sure = static_cast<float>(dp.voxel_map__thresholds__sure_obstacles);
   const float max_dist_idx = static_cast<float>(dp.sepclusters__max_bg_distance / h->sp.voxel_size);
@@ -275,6 +282,7 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
   HIPCHK(hipStreamSynchronize(h->stream));
   const uint32_t P = s.h_small[0];
   s.P = P;
+  tr[0] = ms_since(t0);
   if (P == 0)
     return VOFOD_ERR_EMPTY;  // :1155-1159
   if ((r = sep_ensure_pts(h, P)) != VOFOD_OK)
@@ -296,13 +304,16 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
   if (r != VOFOD_OK)
     return r;
   Workspace& ws = h->sepws;
+  tr[1] = ms_since(t0);
   if ((r = counted_tail(h, ws, hdr.V, P, s.d_sure)) != VOFOD_OK)
     return r;
+  tr[2] = ms_since(t0);
 
   // clusterCloud(vmap_pc_ds, max_voxel_dist) :1171
   const float cmax = static_cast<float>(std::max({h->mg.sx, h->mg.sy, h->mg.sz})) + 2 * lsz;
   if ((r = launch_cluster(h, ws, s.g, 1, static_cast<float>(max_voxel_dist), cmax)) != VOFOD_OK)
     return r;
+  tr[3] = ms_since(t0);
   // sure voxels per cluster :1175-1183 and the latch :1188-1206
   HIPCHK(hipMemsetAsync(s.d_nsure, 0, sizeof(uint32_t) * std::max(hdr.V, 1u), h->stream));
   HIPCHK(hipMemsetAsync(s.d_small + 1, 0, 2 * sizeof(uint32_t), h->stream));
@@ -311,6 +322,9 @@ int sepclusters_begin_locked(vofod_handle* h, int* sure_out)
   KLAUNCH(h, vr::k_any_sure, dim3(gv), dim3(256), ws.d_hdrs, ws.d_labels, s.d_nsure, static_cast<uint32_t>(dp.sepclusters__min_sure_points), s.d_small + 1);
   HIPCHK(hipMemcpyAsync(s.h_small, s.d_small, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (trace)
+    std::fprintf(stderr, "[vofod trace] sepclusters_begin: thresholded cloud (P = %u) %.3f, counted grid (V = %u) %.3f, counts %.3f, clustering enqueued %.3f, end %.3f ms\n", P, tr[0], hdr.V, tr[1], tr[2],
+                 tr[3], ms_since(t0));
   if (s.h_small[1] == 0)
   {
     h->sure_background_sufficient = false;  // :1195
@@ -335,6 +349,8 @@ int sepclusters_finish_locked(vofod_handle* h)
   const float max_dist_idx = static_cast<float>(dp.sepclusters__max_bg_distance / h->sp.voxel_size);
   const int mvd = static_cast<int>(std::ceil(max_dist_idx));
   const float its_diff = static_cast<float>(std::max(h->detection_its - h->sep_start_its, 1));  // :1212
+  static const bool trace = std::getenv("VOFOD_TRACE") != nullptr;
+  const auto t0 = clk::now();
   std::vector<int> offs;  // :1219-1237
   for (int x = -mvd; x <= mvd; x++)
     for (int y = -mvd; y <= mvd; y++)
@@ -362,6 +378,8 @@ int sepclusters_finish_locked(vofod_handle* h)
   const uint32_t oy = static_cast<uint32_t>(std::max(1, std::min(ep.n_offsets / 16, 256)));
   KLAUNCH(h, vr::k_sep_erase, dim3(gv, oy), dim3(256), ep, h->mg, ws.d_hdrs, ws.va.pts, ws.d_labels, s.d_nsure, s.d_offsets, h->d_map);
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (trace)
+    std::fprintf(stderr, "[vofod trace] sepclusters_finish: %d stencil offsets, %.3f ms\n", ep.n_offsets, ms_since(t0));
   h->mapbits_valid = false;
   return VOFOD_OK;
 }
