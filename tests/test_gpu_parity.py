@@ -200,6 +200,36 @@ def test_process_scan_with_apriori_map_detects(oracle, hip, debug, vs=0.5):
         assert ("k_tail_far" in ran or ("k_tail_prep" in ran and "k_explore" in ran and "k_tail_finish" in ran)) and "k_pack" not in ran, ran
 
 
+def test_sensor_stream_with_auto_raycast(oracle, hip):
+    """The nodelet's full schedule on the production call: VOFOD_SCAN_AUTO_RAYCAST without debug output.  The scan's map update,
+    ++its, the raycast role (finish of the pending pass or begin of a new one) and only then the classification
+    (vofod_nodelet.cpp:946-963) - on the HIP side the device tail is launched behind the raycast role.  Detections equal scan
+    by scan; the map within the raycast's float-accumulation tolerance, re-synchronised after every scan."""
+    ref, dev = make_pair(oracle, hip, "os1-128", 0.5)
+    scene = synth.make_scene(21, n_targets=3)
+    ap = synth.apriori_points(scene, 0.5)
+    for d in (ref, dev):
+        d.load_apriori(ap)
+    n_det = n_finished = 0
+    for s in synth.scan_sequence(scene, "os1-128", 6, seed0=300):
+        pending = ref.status().raycast_pending
+        a = ref.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+        b = dev.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+        assert_detections_equal(a, b)
+        n_det += len(a)
+        n_finished += 1 if pending else 0
+        sa, sb = ref.status(), dev.status()
+        assert (sa.raycast_pending, sa.detection_its) == (sb.raycast_pending, sb.detection_its)
+        ma, mb = ref.read_map(capi.MAP_VOXELS), dev.read_map(capi.MAP_VOXELS)
+        fin = np.isfinite(ma)
+        np.testing.assert_array_equal(np.isfinite(mb), fin)
+        # tolerance: float-atomic accumulation order of the ray lengths (SURVEY H8), as in _run_sequence
+        np.testing.assert_allclose(mb[fin], ma[fin], rtol=1e-4, atol=1e-3)
+        np.testing.assert_array_equal(dev.read_map(capi.MAP_FLAGS), ref.read_map(capi.MAP_FLAGS))
+        sync_maps(ref, dev)
+    assert n_det > 0 and n_finished >= 2
+
+
 def test_single_scans_with_more_detections_than_record_slots(oracle, hip):
     """A map-updating scan whose flood fills find more floating clusters than the device tail has record slots (16 per frame):
     the fills have already written their frontiers to the map, so the detections are rebuilt from the clusters and explore

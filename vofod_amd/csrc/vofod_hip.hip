@@ -1746,6 +1746,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ws.rerun = false;
   }
   int ret = VOFOD_OK;
+  bool rc_done = false;  // ++its and the raycast role of VOFOD_SCAN_AUTO_RAYCAST have run ahead of the device tail
   auto t0 = clk::now();
   static const bool trace = std::getenv("VOFOD_TRACE") != nullptr;
   double tr_launch = 0, tr_sync1 = 0, tr_prep = 0, tr_explore = 0, tr_a = 0, tr_b = 0, tr_c = 0;
@@ -1972,7 +1973,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   // (kernels_far.h): close bits from hasCloseTo's stencil with every voxel as its own cluster, then edges and unions around the
   // far voxels only - instead of the six brick kernels over the whole frame.
   const bool dtail_wanted = !switch_off("VOFOD_DEVICE_TAIL");
-  bool far_single = close_first_on && !h->cf_off && !dbg && !no_update && n == 1 && phase == FRAMES_SYNC && !(flags & VOFOD_SCAN_AUTO_RAYCAST) && dtail_wanted && !frame_path && !keep_dirty;
+  bool far_single = close_first_on && !h->cf_off && !dbg && !no_update && n == 1 && phase == FRAMES_SYNC && dtail_wanted && !frame_path && !keep_dirty;
   if (far_single)
   {
     vofod_handle::ClusterTables* ct = nullptr;
@@ -2031,12 +2032,27 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   const bool dtail_on = !switch_off("VOFOD_DEVICE_TAIL");
   // (round 4: a single map-updating scan - the reference's own mode - takes the device tail too: no cluster table down, explore
   // jobs up, results down between the kernels; the flood fills then write their frontiers to the map itself, vofod_nodelet.cpp:1712-1715)
-  // (not under VOFOD_SCAN_AUTO_RAYCAST: that schedule applies the pending raycast update between ++its and the classification,
-  // i.e. between the kernels enqueued here and the tail - the host tail keeps that order)
-  const bool single_update = !no_update && n == 1 && phase == FRAMES_SYNC && !(flags & VOFOD_SCAN_AUTO_RAYCAST);
+  const bool single_update = !no_update && n == 1 && phase == FRAMES_SYNC;
   ws.dtail = dtail_on && !dbg && ((n >= 4 && no_update) || single_update);
   ws.lite = !ws.dtail && lite_on && !dbg && n >= 4 && no_update;
   hipStream_t tail_stream_used = h->stream;  // where the device tail's last operation was enqueued
+  if (ws.dtail && single_update && (flags & VOFOD_SCAN_AUTO_RAYCAST))
+  {
+    // VOFOD_SCAN_AUTO_RAYCAST applies the pending raycast update (or starts a pass) between ++its and the classification
+    // (:949-963), i.e. between the kernels enqueued so far and the tail: the scan's status comes back first (a scan that has to
+    // run again, or failed, must not have moved the raycast state), then the raycast role, then the tail kernels.
+    HIPCHK(hipMemcpyAsync(&ws.h_packed[0].hdr, ws.d_hdrs, sizeof(FrameHdr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (ws.h_packed[0].hdr.status == VOFOD_OK)
+    {
+      h->detection_its++;  // :949
+      if (h->raycast_pending)
+        raycast_finish_locked(h);
+      else
+        raycast_begin_locked(h, &scans[0], tfs);
+      rc_done = true;
+    }
+  }
   if (ws.dtail)
   {
     // Classification tail on the device (kernels_tail.h): boxes + gates, flood fills, detection records; nothing comes back
@@ -2228,7 +2244,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
       ws.job_n = n;
       return CCL_RETRY_STATUS;
     }
-  if (!no_update)
+  if (!no_update && !rc_done)
   {
     h->detection_its++;  // :949
     if (flags & VOFOD_SCAN_AUTO_RAYCAST)
