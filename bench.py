@@ -628,17 +628,23 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F, V_far=0.0):
 def kernel_source_sha():
     """hash of the kernel sources: ties a PMC traffic summary to the code it was measured on.  Comments and white space do not
     count (a corrected comment is not a new kernel): // and /* */ comments are cut and runs of white space collapsed before
-    hashing - crude on purpose (a "//" inside a string literal is cut too): the hash only has to change when the code does."""
+    hashing - crude on purpose (a "//" inside a string literal is cut too): the hash only has to change when the code does.
+    The files with the device code of the per-scan path count (kernels_*.h, the structures they share in common.h, the device
+    eigen-solver); the host driver (vofod_hip.hip, driver_aux.h, collective.h, thread_pool.h, host_tail.h) does not: a change of
+    the sepclusters role's allocation policy is not a new frame kernel."""
     import hashlib
     import re
 
     hsh = hashlib.sha1()
-    for f in sorted((ROOT / "vofod_amd" / "csrc").glob("*.h")) + sorted((ROOT / "vofod_amd" / "csrc").glob("*.hip")):
+    csrc = ROOT / "vofod_amd" / "csrc"
+    for f in sorted(csrc.glob("kernels_*.h")) + [csrc / "common.h", csrc / "eigsolve3.h"]:
+        if not f.exists():
+            continue
         text = f.read_text(errors="replace")
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
         text = re.sub(r"//[^\n]*", " ", text)
         hsh.update(f.name.encode() + b"\0" + " ".join(text.split()).encode())
-    return "c1:" + hsh.hexdigest()
+    return "c2:" + hsh.hexdigest()
 
 
 def cpu_baseline(args, gpu_det, host_scans):

@@ -86,11 +86,13 @@ def test_kernel_source_hash_ignores_comments_and_layout(tmp_path, monkeypatch):
     bench = importlib.import_module("bench")
     src = tmp_path / "vofod_amd" / "csrc"
     src.mkdir(parents=True)
-    (src / "a.h").write_text("// a comment\nint f(int x) { return x + 1; }  /* another */\n")
-    (src / "b.hip").write_text("__global__ void k() {}\n")
+    (src / "kernels_a.h").write_text("// a comment\nint f(int x) { return x + 1; }  /* another */\n")
+    (src / "driver.hip").write_text("int host_side() { return 1; }\n")
     monkeypatch.setattr(bench, "ROOT", tmp_path)
     h0 = bench.kernel_source_sha()
-    (src / "a.h").write_text("// a corrected comment\nint f(int x)\n{\n  return x + 1;\n}\n")
+    (src / "kernels_a.h").write_text("// a corrected comment\nint f(int x)\n{\n  return x + 1;\n}\n")
     assert bench.kernel_source_sha() == h0
-    (src / "a.h").write_text("int f(int x) { return x + 2; }\n")
+    (src / "driver.hip").write_text("int host_side() { return 2; }\n")  # the host driver holds no kernel of the path
+    assert bench.kernel_source_sha() == h0
+    (src / "kernels_a.h").write_text("int f(int x) { return x + 2; }\n")
     assert bench.kernel_source_sha() != h0

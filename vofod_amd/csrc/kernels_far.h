@@ -1,16 +1,19 @@
 // Close-first clustering on the general path (round 4): a single map-updating scan - the reference's own mode.
 //
 // The batched frame kernel gets a voxel's close bit from the dilated map image; a sensor stream changes the map with every scan,
-// so the image is never valid.  Here the close bits come from hasCloseTo's stencil itself (k_closefar / k_closefar_sweep with
+// so that image (140 us to build) is never valid.  Here the close bits come from hasCloseTo's stencil itself (k_closefar / k_closefar_sweep with
 // every voxel as its own "cluster": the own map row first, the other rows of the stencil only for the few voxels that row leaves
 // undecided), and only the FAR voxels - those the sweep finds nothing for, typically 1-2 % of a scan - are clustered:
 //   k_far_edges   one thread per (far voxel, row of the clustering stencil, direction): the occupancy bitmap window of that row
 //                 (as k_union), neighbours within the tolerance (sure by the lattice distance, FLANN's float expression on the
 //                 boundary); a CLOSE neighbour taints the voxel, a far one is joined (lock-free union-find, forward rows only);
 //   k_far_final   one workgroup: taint of every component, sizes / lattice boxes of the surviving ones (= far_clusters_indices of
-//                 vofod_nodelet.cpp:746), their records and candidate members; a tainted voxel is close from here on;
+//                 vofod_nodelet.cpp:746), their records and candidate members - candidates first, in the canonical order, members
+//                 cluster by cluster with ascending rank: the lists k_frame_lds_far leaves, read by the same k_tail_far; a
+//                 tainted voxel is close from here on;
 //   k_finalize_far updateVMaps (:943-950) voxel by voxel: scores/point + flag 2 for close voxels, scores/unknown + flag 3 for the
-//                 voxels of far clusters - what k_finalize does through cluster labels.
+//                 voxels of far clusters - what k_finalize does through cluster labels; the map's occupancy image (one bit per
+//                 cell, k_mapbits) and its counters are patched where the update flips a cell.
 // A far voxel's component is a far cluster iff it has no edge to a close voxel: the argument of kernels_frame.h, on voxels
 // instead of bricks (no clique assumption: any tolerance / leaf).  More than FAR_MAX far voxels (a cold map) raise
 // CF_RETRY_STATUS: the scan is run again through the full clustering.
