@@ -133,3 +133,66 @@ def test_message_serialisation_byte_layout():
     assert buf[: n.value].tobytes() == hdr_bytes + bytes([1, 0])
     assert hip.serialize_profiling_info(12, 34, 5, 6, 2, capi.ptr(buf), buf.size, C.byref(n)) == capi.OK
     assert buf[: n.value].tobytes() == struct.pack("<IIIQB", 12, 34, 5, 6, 2) and n.value == 21
+
+
+@pytest.mark.parametrize("sensor,vs,seed", [("os1-16", 0.5, 3), ("os1-16", 0.25, 4), ("os1-128", 0.5, 5)])
+def test_far_clusters_are_the_untainted_components_of_the_far_voxels(oracle, sensor, vs, seed):
+    """The claim the close-first kernels rest on (kernels_frame.h, kernels_far.h), checked on the ORACLE's own
+    output with scipy: the far clusters of findCloseFarClusters (vofod_nodelet.cpp:727-748: a cluster is close as soon as ANY
+    member has a background voxel within hasCloseTo's stencil) are exactly the connected components of the FAR voxels (own
+    hasCloseTo false) that have no edge d^2 < tol^2 to a close voxel - same member sets, hence same sizes, smallest members and
+    order.  Nothing of the HIP library takes part."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import cKDTree
+
+    from vofod_amd import synth
+    from vofod_amd.detector import VoFOD, default_params
+
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    det = VoFOD(oracle, sp, dp)
+    scene = synth.make_scene(seed, n_targets=6)
+    warm = synth.make_scene(seed, n_targets=0)  # same buildings, no targets: the targets stay far from the background
+    synth.warm_map(det, warm, sensor, 6, seed0=700)
+    s = synth.scan_sequence(scene, sensor, 1, seed0=800)[0]
+    _, dbg = det.process_scan(s.scan, s.tf, flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+    pts = np.stack([dbg["weighted"]["x"], dbg["weighted"]["y"], dbg["weighted"]["z"]], axis=1).astype(np.float32)
+    V = len(pts)
+    labels, cl = dbg["labels"], dbg["clusters"]
+    assert V > 200 and (cl["is_close"] == 0).any() and (cl["is_close"] == 1).any()
+    tol = np.float32(dp.ground_points_max_distance)
+    thr = np.float32(dp.voxel_map__thresholds__new_obstacles)
+    f = oracle.extra("vofod_oracle_map_has_close_to", C.c_int, [C.c_void_p] + [C.c_float] * 5)
+    close = np.array([bool(f(det.h, float(p[0]), float(p[1]), float(p[2]), float(tol), float(thr))) for p in pts])
+    # edges: FLANN's L2_Simple in float32 (diff * diff accumulated in x, y, z order), strict < tol^2 (SURVEY H6)
+    pairs = cKDTree(pts.astype(np.float64)).query_pairs(float(tol) * 1.001, output_type="ndarray")
+    d = pts[pairs[:, 0]] - pts[pairs[:, 1]]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]
+    pairs = pairs[d2 < tol * tol]
+    a, b = pairs[:, 0], pairs[:, 1]
+    # the oracle's clustering is the component structure of this graph (clusterCloud :932)
+    n_all, comp_all = connected_components(coo_matrix((np.ones(len(a)), (a, b)), shape=(V, V)), directed=False)
+    first = np.full(n_all, V, dtype=np.int64)
+    np.minimum.at(first, comp_all, np.arange(V))
+    np.testing.assert_array_equal(first[comp_all], labels)
+    # close first: taint from edges between a far and a close voxel, components of the far-far edges
+    far = ~close
+    taint = np.zeros(V, dtype=bool)
+    mixed = far[a] != far[b]
+    taint[np.where(far[a], a, b)[mixed]] = True
+    ff = far[a] & far[b]
+    _, comp = connected_components(coo_matrix((np.ones(int(ff.sum())), (a[ff], b[ff])), shape=(V, V)), directed=False)
+    comp_tainted = np.zeros(comp.max() + 1, dtype=bool)
+    np.logical_or.at(comp_tainted, comp[far], taint[far])
+    survivors = far & ~comp_tainted[comp]
+    far_labels = cl["first_member"][cl["is_close"] == 0]
+    np.testing.assert_array_equal(survivors, np.isin(labels, far_labels))
+    # ... and component by component: the same member sets (hence sizes, smallest members, order)
+    for lab in far_labels:
+        members = np.flatnonzero(labels == lab)
+        assert len(set(comp[members])) == 1 and (comp == comp[members[0]]).sum() == len(members)
+    det.close()
