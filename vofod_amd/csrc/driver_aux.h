@@ -195,7 +195,7 @@ int voxelize_cloud(vofod_handle* h, Workspace& ws, const vofod_cloud_view* in, G
   // Growth with headroom: a workspace grows by releasing and allocating its three dozen arrays (2.6 ms), and the cloud of
   // updateSeparatedBGClusters - the map's background voxels - gains a few thousand points from one call to the next while the map
   // warms: sized to the point, EVERY call of the role paid that (VOFOD_TRACE: 2.7 of the role's 2.9 ms).
-  const uint32_t want = n > ws.pt_cap ? n + n / 2 + 4096u : std::max(n, 1u);
+  const uint32_t want = n > std::min(ws.pt_cap, ws.vox_cap) ? n + n / 2 + 4096u : std::max(n, 1u);
   if (hipError_t e = ws.ensure(1, want, want, std::max(ws.words_cap, 1u << 16)); e != hipSuccess)
   {
     h->err = std::string("workspace allocation: ") + hipGetErrorString(e);
