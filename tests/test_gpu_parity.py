@@ -215,7 +215,14 @@ def test_sensor_stream_with_auto_raycast(oracle, hip):
         pending = ref.status().raycast_pending
         a = ref.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
         b = dev.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
-        assert_detections_equal(a, b)
+        assert len(a) == len(b)
+        for k in ("id", "frame", "n_points"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_allclose(a["position"], b["position"], atol=1e-3)
+        # tolerance: the classification reads a map the raycast update has just changed - the uncertainty sum inherits the float
+        # accumulation order of the ray lengths: 1e-4 relative here, 1e-5 where the maps are identical
+        np.testing.assert_allclose(a["confidence"], b["confidence"], rtol=1e-4, atol=1e-300)
+        np.testing.assert_allclose(a["detection_probability"], b["detection_probability"], rtol=1e-5)
         n_det += len(a)
         n_finished += 1 if pending else 0
         sa, sb = ref.status(), dev.status()
