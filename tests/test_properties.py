@@ -196,3 +196,60 @@ def test_far_clusters_are_the_untainted_components_of_the_far_voxels(oracle, sen
         members = np.flatnonzero(labels == lab)
         assert len(set(comp[members])) == 1 and (comp == comp[members[0]]).sum() == len(members)
     det.close()
+
+
+@settings(max_examples=80, deadline=None)
+@given(seed=st.integers(0, 100_000), p_unknown=st.sampled_from([0.15, 0.25, 0.3, 0.4, 0.6]), p_ground=st.sampled_from([0.0, 0.01, 0.05]), R=st.integers(2, 14))
+def test_explore_to_ground_against_scipy_labelling(oracle, seed, p_unknown, p_ground, R):
+    """exploreToGround (voxel_map.cpp:402-488) on random maps against scipy.ndimage: the walk spreads through UNKNOWN voxels
+    (unknown_thr < v <= ground_thr, 6-neighbourhood, Manhattan distance <= R from the start); it is "connected" iff a voxel it
+    pops lies above the ground threshold or an unknown voxel at distance exactly R - 1 is popped; otherwise it returns the
+    unknown voxels it popped (some twice: SURVEY Q7) - as a set, the start's component.  The depth-first order does not matter
+    for any of this, which is what the wave-parallel fill of kernels_classify.h relies on."""
+    from scipy import ndimage
+
+    from vofod_amd.detector import VoFOD, default_params
+
+    sp, dp = default_params(oracle)
+    sp.voxel_size = 0.5
+    sp.oparea_offset[:] = (5.0, 5.0, 0.0)
+    sp.oparea_size[:] = (10.0, 10.0, 10.0)
+    sp.sensor_hrays, sp.sensor_vrays = 8, 2
+    det = VoFOD(oracle, sp, dp)
+    sx, sy, sz = det.map_size
+    rng = np.random.default_rng(seed)
+    u = rng.random((sz, sy, sx))
+    m = np.full((sz, sy, sx), -1000.0, dtype=np.float32)  # air
+    m[u < p_unknown] = -740.0                              # unknown
+    m[u > 1.0 - p_ground] = 0.0                            # ground / obstacles
+    o = tuple(int(v) for v in rng.integers(3, [sx - 3, sy - 3, sz - 3]))
+    if rng.random() < 0.8:
+        m[o[2], o[1], o[0]] = -740.0
+    det.write_map(capi.MAP_VOXELS, m)
+    f = oracle.extra("vofod_oracle_map_explore_to_ground", C.c_int, [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)])
+    buf = np.zeros((8192, 3), dtype=np.int32)
+    n = C.c_size_t(0)
+    off = det.map_offset
+    c = [off[a] + (o[a] + 0.5) * 0.5 for a in range(3)]
+    conn = bool(f(det.h, c[0], c[1], c[2], -750.0, -300.0, float(R), capi.ptr(buf), 8192, C.byref(n)))
+    got = {tuple(r) for r in buf[: n.value].tolist()}
+
+    zz, yy, xx = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+    manh = np.abs(xx - o[0]) + np.abs(yy - o[1]) + np.abs(zz - o[2])
+    ball = manh <= R
+    unknown = (m > -750.0) & (m <= -300.0)
+    ground = m > -300.0
+    start_unknown = bool(unknown[o[2], o[1], o[0]])
+    if ground[o[2], o[1], o[0]]:
+        want_conn, want = True, set()
+    elif not start_unknown:
+        want_conn, want = False, set()  # popped, neither ground nor unknown: nothing spreads
+    else:
+        lab, _ = ndimage.label(unknown & ball)  # 6-neighbourhood by default
+        comp = lab == lab[o[2], o[1], o[0]]
+        popped = ndimage.binary_dilation(comp) & ball  # the component and everything it pushes
+        want_conn = bool((popped & ground).any() or (comp & (manh == R - 1)).any())
+        want = set() if want_conn else {(int(x), int(y), int(z)) for z, y, x in zip(*np.nonzero(comp))}
+    assert conn == want_conn
+    assert got == want
+    det.close()
