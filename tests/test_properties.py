@@ -253,3 +253,44 @@ def test_explore_to_ground_against_scipy_labelling(oracle, seed, p_unknown, p_gr
     assert conn == want_conn
     assert got == want
     det.close()
+
+
+@settings(max_examples=150, deadline=None)
+@given(seed=st.integers(0, 1_000_000), length=st.floats(0.05, 9.0))
+def test_ray_walk_is_the_geometric_intersection_of_the_segment_with_the_lattice(oracle, seed, length):
+    """forEachRay (voxel_map.cpp:229-263, Amanatides-Woo) for random rays inside the default map, against plain geometry: the
+    pieces tile the segment (their lengths are >= 0 and sum to the ray's length), consecutive voxels differ by one step along one
+    axis in the ray's direction, and the middle of every piece of positive length lies inside the voxel it was charged to."""
+    from vofod_amd.detector import VoFOD
+
+    big = VoFOD(oracle)  # 241 x 201 x 51 voxels of 0.5 m, offset (-20, -30, -1.25)
+    f = oracle.extra("vofod_oracle_map_ray", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)])
+    rng = np.random.default_rng(seed)
+    off = np.float64(big.map_offset)
+    start = (off + np.float64([40.0, 40.0, 12.0]) + rng.uniform(-3, 3, 3)).astype(np.float32)  # >= 9 m from every face
+    d = rng.normal(size=3)
+    if rng.random() < 0.2:
+        d[rng.integers(0, 3)] = 0.0  # axis-parallel planes: an infinite tmax on that axis
+    if not np.any(d):
+        d[0] = 1.0
+    d = (d / np.linalg.norm(d)).astype(np.float32)
+    vox = np.zeros((256, 3), dtype=np.int32)
+    dd = np.zeros(256, dtype=np.float32)
+    n = C.c_size_t(0)
+    f(big.h, capi.ptr(start), capi.ptr(d), np.float32(length), capi.ptr(vox), capi.ptr(dd), 256, C.byref(n))
+    k = n.value
+    assert 0 < k < 256
+    v, w = vox[:k].astype(np.int64), dd[:k].astype(np.float64)
+    assert (w >= -1e-6).all()
+    assert abs(w.sum() - np.float32(length)) < 1e-4
+    first = np.floor((start.astype(np.float64) - off) / 0.5).astype(np.int64)
+    np.testing.assert_array_equal(v[0], first)
+    steps = np.diff(v, axis=0)
+    assert (np.abs(steps).sum(axis=1) == 1).all()            # one axis at a time
+    assert (steps * np.sign(d.astype(np.float64)) >= 0).all()  # never against the ray
+    t1 = np.cumsum(w)
+    mid = start.astype(np.float64) + d.astype(np.float64) * (t1 - 0.5 * w)[:, None]
+    cell = (mid - off) / 0.5
+    inside = (cell >= v - 1e-4) & (cell <= v + 1 + 1e-4)
+    assert inside[w > 1e-4].all()
+    big.close()
