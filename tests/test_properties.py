@@ -294,3 +294,74 @@ def test_ray_walk_is_the_geometric_intersection_of_the_segment_with_the_lattice(
     inside = (cell >= v - 1e-4) & (cell <= v + 1 + 1e-4)
     assert inside[w > 1e-4].all()
     big.close()
+
+
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 100_000), n=st.integers(1, 5000), leaf=st.sampled_from([0.1, 0.25, 0.5, 1.0]), aligned=st.booleans())
+def test_weighted_grid_against_numpy_unique(oracle, seed, n, leaf, aligned):
+    """VoxelGridWeighted's sort + run-length pass against numpy: with the lattice the call reports (offset, div_b), the cell of a
+    point is floor((p - offset) * inv_leaf) in float32 (voxel_grid_weighted.cpp:131-133), the key i + j*dx + k*dx*dy (:136);
+    np.unique of those keys gives the occupied voxels in the output's order, their multiplicities the weights, and the output
+    positions are the voxel centres (i + 0.5) * leaf + offset (:175-177), every operation rounded to float32."""
+    q = _cloud(seed, n, 25.0)
+    if seed % 3 == 0:
+        q = np.round(q * 4) / 4  # points on cell boundaries
+        q = q.astype(np.float32)
+    align = (-19.75, -29.75, -1.0) if aligned else None
+    out, keys, grid, _ = voxel_grid_weighted(oracle, q[:, 0], q[:, 1], q[:, 2], leaf, align)
+    off = np.float32(list(grid.offset))
+    div = np.int64(list(grid.div_b))
+    inv = np.float32(1.0) / np.float32(leaf)
+    cell = np.floor(((q - off).astype(np.float32) * inv).astype(np.float32)).astype(np.int64)
+    assert (cell >= 0).all() and (cell < div).all()
+    k = cell[:, 0] + cell[:, 1] * div[0] + cell[:, 2] * div[0] * div[1]
+    uk, first, counts = np.unique(k, return_index=True, return_counts=True)
+    np.testing.assert_array_equal(keys.astype(np.int64), uk)
+    np.testing.assert_array_equal(out["range"].astype(np.int64), counts)
+    c = cell[first].astype(np.float32)
+    lf = np.float32(leaf)
+    centre = (((c + np.float32(0.5)).astype(np.float32) * lf).astype(np.float32) + off).astype(np.float32)
+    got = np.stack([out["x"], out["y"], out["z"]], axis=1)
+    np.testing.assert_array_equal(got.view(np.uint32), centre.view(np.uint32))
+
+
+@settings(max_examples=12, deadline=None)
+@given(seed=st.integers(0, 100_000), p_bg=st.sampled_from([0.002, 0.01, 0.05]), max_dist=st.sampled_from([0.5, 1.0, 1.5, 1.7]))
+def test_has_close_to_is_a_dilation_of_the_occupancy_image(oracle, seed, p_bg, max_dist):
+    """hasCloseTo (voxel_map.cpp:376-400) at EVERY cell of a small map against scipy's binary dilation of the thresholded map by
+    the stencil {o in [-d, d)^3 : floor(sqrt(|o|^2)) <= max_dist / vs} (half-open cube, truncated integer norm: SURVEY Q3 / Q4),
+    cut at the map's faces - i.e. the answer depends on the cell only and is one bit of a dilated image, which is what k_dilate
+    builds once per map state and the frame kernel reads (`mapclose`)."""
+    from scipy import ndimage
+
+    from vofod_amd.detector import VoFOD, default_params
+
+    sp, dp = default_params(oracle)
+    sp.voxel_size = 0.5
+    sp.oparea_offset[:] = (3.0, 3.0, 0.0)
+    sp.oparea_size[:] = (6.0, 6.0, 6.0)
+    sp.sensor_hrays, sp.sensor_vrays = 8, 2
+    det = VoFOD(oracle, sp, dp)
+    sx, sy, sz = det.map_size
+    rng = np.random.default_rng(seed)
+    m = np.full((sz, sy, sx), -1000.0, dtype=np.float32)
+    m[rng.random((sz, sy, sx)) < p_bg] = 0.0
+    det.write_map(capi.MAP_VOXELS, m)
+    thr = -300.0
+    f = oracle.extra("vofod_oracle_map_has_close_to", C.c_int, [C.c_void_p] + [C.c_float] * 5)
+    off = det.map_offset
+    got = np.zeros((sz, sy, sx), dtype=bool)
+    for k in range(sz):
+        for j in range(sy):
+            for i in range(sx):
+                got[k, j, i] = bool(f(det.h, off[0] + (i + 0.5) * 0.5, off[1] + (j + 0.5) * 0.5, off[2] + (k + 0.5) * 0.5, max_dist, thr))
+    mdi = np.float32(max_dist) * np.float32(2.0)  # max_dist * vs_inv
+    d = int(np.ceil(mdi))
+    # structuring element over offsets -d .. d (scipy wants odd sizes): the +d plane stays empty (half-open cube)
+    o = np.arange(-d, d + 1)
+    oz, oy, ox = np.meshgrid(o, o, o, indexing="ij")
+    S = (np.floor(np.sqrt((ox * ox + oy * oy + oz * oz).astype(np.float64))).astype(np.float32) <= mdi) & (ox < d) & (oy < d) & (oz < d)
+    # close(c) = OR over o in S of occ(c + o): a dilation by the REFLECTED stencil (scipy's convention is occ(c - o))
+    want = ndimage.binary_dilation(m > thr, structure=S[::-1, ::-1, ::-1])
+    np.testing.assert_array_equal(got, want)
+    det.close()
