@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void k_far_edges(const GridParams g, const Clu
   if (!win)
     return;
   const unsigned long long win0 = win;
-  const uint32_t pre = wprefix[wi] + __popcll(w0 & ((1ull << sh) - 1ull));
+  // rank of the window's first set bit.  With GridParams::sparse_prefix (the brick family's emission) k_emit leaves the prefix
+  // entries of all-empty bitmap blocks unwritten: a window may START in the last word of such a block with all its bits in the
+  // next word, whose block is not empty - that word's own entry is the rank then (wprefix[wi] was stale memory there)
+  const uint32_t pre = w0 ? wprefix[wi] + __popcll(w0 & ((1ull << sh) - 1ull)) : wprefix[wi + 1];
   const float4 pv = va.pts[v];
   bool tainted = false;
   while (win)

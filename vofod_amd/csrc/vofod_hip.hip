@@ -306,6 +306,8 @@ struct Workspace
   PackedLite* h_lite = nullptr;  // pinned
   bool lite = false;  // the batch in this workspace was read back through the lite slots (no debug output asked for)
   bool mapbits_patched = false;  // k_finalize_far kept the map's occupancy image and counters up to date with this scan's update
+  bool prof_deferred = false;  // VOFOD_LDS_PROF=2: the frame kernel's stamps of this batch are printed when it is collected
+  uint32_t prof_slot0 = 0;
   bool far_ran = false;  // launch_cluster ran k_frame_lds_far: the cluster table and the member list are in the order k_tail_far reads
   int close_first = 0;  // k_frame_lds: 1 = cluster the far voxels only (read-only batches), 2 = the same with labels for the far-only debug view
   bool dtail = false;  // ... or its classification tail ran on the device (kernels_tail.h): only detection records come back
@@ -1346,6 +1348,93 @@ bool plan_lds_ccl(const vofod_handle* h, const vofod_handle::ClusterTables* ct, 
   return allow_lds && lds_on && want_bricks(ct, ws) && ct->lds_ok && !h->lds_ccl_off;
 }
 
+// VOFOD_LDS_PROF (diagnostics): phase durations of the frame kernel's workgroups from the 100 MHz wall clock stamps in slots
+// [s0, s0 + cnt) of the handle's stamp buffer.  =1: after every launch (the stream is synchronised: one batch at a time); =2: when the
+// batch is collected (batches in flight keep their own slots: the phases as they last in the pipeline).
+int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
+{
+  unsigned long long* d_prof = h->d_prof_ccl;
+  std::vector<unsigned long long> t(32 * cnt);
+  if (sync)
+    HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(t.data(), d_prof + 32 * static_cast<size_t>(s0), sizeof(unsigned long long) * 32 * cnt, hipMemcpyDeviceToHost));
+  static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "adjacent", "far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
+  std::vector<std::pair<double, uint32_t>> byd;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (uint32_t f = 0; f < cnt; f++)
+  {
+    if (!t[32 * f + 13])
+      continue;
+    byd.push_back({(t[32 * f + 13] - t[32 * f]) * 0.01, f});
+    t0 = std::min(t0, t[32 * f]);
+    t1 = std::max(t1, t[32 * f + 13]);
+  }
+  std::sort(byd.begin(), byd.end());
+  double mean = 0;
+  for (auto& b : byd)
+    mean += b.first / byd.size();
+  for (size_t q : {size_t(0), byd.size() / 2, byd.size() - 1})
+  {
+    if (byd.empty())
+      break;
+    const uint32_t f = byd[q].second;
+    if (t[32 * f + 31] == ~0ull)
+    {
+      // a close-first frame: its own phases behind the emission
+      auto us = [&](int a, int b) { return (t[32 * f + b] - t[32 * f + a]) * 0.01; };
+      std::fprintf(stderr,
+                   "[k_frame_lds_far] frame %u: %.1f us | keys %llu V %llu bricks %llu pure-far bricks %llu far clusters %llu candidate members %llu | bits %.1f prefix %.1f words %.1f closebits %.1f count "
+                   "%.1f rank-a/b %.1f rank-c %.1f emit %.1f extras %.1f near+far %.1f open %.1f stats %.1f table %.1f members %.1f\n",
+                   f, byd[q].first, t[32 * f + 27], t[32 * f + 29], t[32 * f + 26], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30], us(0, 1), us(1, 2), us(2, 3), us(3, 15), us(15, 14), us(14, 4), us(4, 5),
+                   us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 13));
+      continue;
+    }
+    std::fprintf(stderr, "[k_frame_lds] frame %u: %.1f us | keys %llu V %llu bricks %llu extras %llu hits %llu open %llu surviving %llu |", f, byd[q].first, t[32 * f + 27], t[32 * f + 29],
+                 t[32 * f + 26], t[32 * f + 28], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30]);
+    for (int i = 0; i < 13; i++)
+      std::fprintf(stderr, " %s %.1f", names[i], (t[32 * f + i + 1] - t[32 * f + i]) * 0.01);
+    std::fprintf(stderr, " (count %.1f of rank-a/b; %llu bricks outside the largest component, %llu far hits)\n", (t[32 * f + 14] - t[32 * f + 3]) * 0.01, t[32 * f + 31] & 0xffffffffull,
+                 t[32 * f + 31] >> 32);
+  }
+  if (!byd.empty())
+    std::fprintf(stderr, "[k_frame_lds] %zu workgroups: span %.1f us, mean %.1f us\n", byd.size(), (t1 - t0) * 0.01, mean);
+  // VOFOD_LDS_PROF_JSON=<file>: the phase table of the close-first frames of this launch (mean / median / max over the
+  // frames, us), one JSON object per launch appended to the file - profiles/r05_frame_phases.json is made of these
+  if (const char* jf = std::getenv("VOFOD_LDS_PROF_JSON"); jf && !byd.empty() && t[32 * byd[0].second + 31] == ~0ull)
+  {
+    static const int cuts[][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 15}, {15, 14}, {14, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}, {11, 13}, {0, 13}};
+    static const char* cnames[] = {"bits", "prefix", "words", "closebits", "count", "rank_ab", "rank_c", "emit", "extras_restore", "cf_edges", "cf_open", "cf_stats", "cf_table", "cf_members", "total"};
+    if (FILE* fp = std::fopen(jf, "a"))
+    {
+      std::fprintf(fp, "{\"frames\": %zu, \"span_us\": %.1f, \"phases\": {", byd.size(), (t1 - t0) * 0.01);
+      for (size_t c = 0; c < sizeof(cuts) / sizeof(cuts[0]); c++)
+      {
+        std::vector<double> v;
+        for (auto& b : byd)
+          v.push_back((t[32 * b.second + cuts[c][1]] - t[32 * b.second + cuts[c][0]]) * 0.01);
+        std::sort(v.begin(), v.end());
+        double m = 0;
+        for (double x : v)
+          m += x / v.size();
+        std::fprintf(fp, "%s\"%s\": {\"mean\": %.2f, \"median\": %.2f, \"p90\": %.2f, \"max\": %.2f}", c ? ", " : "", cnames[c], m, v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+      }
+      // where in time the frames' workgroups started and ended relative to the first start (one CU per frame: late starts = a busy chip)
+      std::vector<double> st, en;
+      for (auto& b : byd)
+      {
+        st.push_back((t[32 * b.second] - t0) * 0.01);
+        en.push_back((t[32 * b.second + 13] - t0) * 0.01);
+      }
+      std::sort(st.begin(), st.end());
+      std::sort(en.begin(), en.end());
+      std::fprintf(fp, "}, \"start_us\": {\"median\": %.1f, \"max\": %.1f}, \"end_us\": {\"median\": %.1f, \"max\": %.1f}}\n", st[st.size() / 2], st.back(), en[en.size() / 2], en.back());
+      std::fclose(fp);
+    }
+  }
+  HIPCHK(hipMemset(d_prof + 32 * static_cast<size_t>(s0), 0, sizeof(unsigned long long) * 32 * cnt));
+          return VOFOD_OK;
+  }
+
 // K7: Euclidean clustering of the frames in `ws`
 int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t n, float tol, float cmax, bool allow_lds = false, const unsigned long long* mapclose = nullptr,
                    const UpdateParams* up_tables = nullptr)
@@ -1369,64 +1458,28 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
     {
       (void)allow_lds;
       ws.lean_emit = false;
-      unsigned long long*& d_prof = h->d_prof_ccl;
-      if (!d_prof && std::getenv("VOFOD_LDS_PROF"))
+      unsigned long long*& d_prof_all = h->d_prof_ccl;
+      if (!d_prof_all && std::getenv("VOFOD_LDS_PROF"))
       {
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof), sizeof(unsigned long long) * 32 * 4096));
-        HIPCHK(hipMemset(d_prof, 0, sizeof(unsigned long long) * 32 * 4096));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_prof_all), sizeof(unsigned long long) * 32 * 4096));
+        HIPCHK(hipMemset(d_prof_all, 0, sizeof(unsigned long long) * 32 * 4096));
       }
+      // VOFOD_LDS_PROF=2: a submitted batch keeps the stamps in its ticket's slots and prints them when it is collected - the
+      // phases as they last with the other batches' kernels beside them (=1 synchronises behind every launch)
+      ws.prof_deferred = false;
+      uint32_t prof_slot0 = 0;
+      if (d_prof_all && std::atoi(std::getenv("VOFOD_LDS_PROF") ? std::getenv("VOFOD_LDS_PROF") : "0") == 2 && ws.F <= 256)
+        for (int t = 0; t < vofod_handle::MAX_INFLIGHT; t++)
+          if (&ws == h->slot(t))
+          {
+            ws.prof_deferred = true;
+            prof_slot0 = 256u * static_cast<uint32_t>(t);
+          }
+      ws.prof_slot0 = prof_slot0;
+      unsigned long long* d_prof = d_prof_all ? d_prof_all + 32 * static_cast<size_t>(prof_slot0) : nullptr;
       if (ws.frame_fused)
       {
         ws.frame_fused = false;
-        auto print_prof = [&](uint32_t s0, uint32_t cnt) -> int {
-
-          // VOFOD_LDS_PROF=1 (diagnostics): phase durations from the 100 MHz wall clock
-          std::vector<unsigned long long> t(32 * cnt);
-          HIPCHK(hipStreamSynchronize(h->stream));
-          HIPCHK(hipMemcpy(t.data(), d_prof + 32 * static_cast<size_t>(s0), sizeof(unsigned long long) * 32 * cnt, hipMemcpyDeviceToHost));
-          static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "adjacent", "far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
-          std::vector<std::pair<double, uint32_t>> byd;
-          unsigned long long t0 = ~0ull, t1 = 0;
-          for (uint32_t f = 0; f < cnt; f++)
-          {
-            if (!t[32 * f + 13])
-              continue;
-            byd.push_back({(t[32 * f + 13] - t[32 * f]) * 0.01, f});
-            t0 = std::min(t0, t[32 * f]);
-            t1 = std::max(t1, t[32 * f + 13]);
-          }
-          std::sort(byd.begin(), byd.end());
-          double mean = 0;
-          for (auto& b : byd)
-            mean += b.first / byd.size();
-          for (size_t q : {size_t(0), byd.size() / 2, byd.size() - 1})
-          {
-            if (byd.empty())
-              break;
-            const uint32_t f = byd[q].second;
-            if (t[32 * f + 31] == ~0ull)
-            {
-              // a close-first frame: its own phases behind the emission
-              auto us = [&](int a, int b) { return (t[32 * f + b] - t[32 * f + a]) * 0.01; };
-              std::fprintf(stderr,
-                           "[k_frame_lds_far] frame %u: %.1f us | keys %llu V %llu bricks %llu pure-far bricks %llu far clusters %llu candidate members %llu | bits %.1f prefix %.1f words %.1f closebits %.1f count "
-                           "%.1f rank-a/b %.1f rank-c %.1f emit %.1f extras %.1f near+far %.1f open %.1f stats %.1f table %.1f members %.1f\n",
-                           f, byd[q].first, t[32 * f + 27], t[32 * f + 29], t[32 * f + 26], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30], us(0, 1), us(1, 2), us(2, 3), us(3, 15), us(15, 14), us(14, 4), us(4, 5),
-                           us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 13));
-              continue;
-            }
-            std::fprintf(stderr, "[k_frame_lds] frame %u: %.1f us | keys %llu V %llu bricks %llu extras %llu hits %llu open %llu surviving %llu |", f, byd[q].first, t[32 * f + 27], t[32 * f + 29],
-                         t[32 * f + 26], t[32 * f + 28], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30]);
-            for (int i = 0; i < 13; i++)
-              std::fprintf(stderr, " %s %.1f", names[i], (t[32 * f + i + 1] - t[32 * f + i]) * 0.01);
-            std::fprintf(stderr, " (count %.1f of rank-a/b; %llu bricks outside the largest component, %llu far hits)\n", (t[32 * f + 14] - t[32 * f + 3]) * 0.01, t[32 * f + 31] & 0xffffffffull,
-                         t[32 * f + 31] >> 32);
-          }
-          if (!byd.empty())
-            std::fprintf(stderr, "[k_frame_lds] %zu workgroups: span %.1f us, mean %.1f us\n", byd.size(), (t1 - t0) * 0.01, mean);
-          HIPCHK(hipMemset(d_prof + 32 * static_cast<size_t>(s0), 0, sizeof(unsigned long long) * 32 * cnt));
-                  return VOFOD_OK;
-        };
         ws.far_ran = up_tables && mapclose && ws.close_first;
         if (ws.far_ran)  // read-only batches: cluster the far voxels only (the close-first instantiation)
           KLAUNCH(h, k_frame_lds_far, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
@@ -1435,8 +1488,8 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
           KLAUNCH(h, k_frame_lds_full, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
                   mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, 0);
         ws.finalize_fused = up_tables && mapclose;
-        if (d_prof)
-          if (const int pr = print_prof(0, n); pr != VOFOD_OK)
+        if (d_prof && !ws.prof_deferred)
+          if (const int pr = print_frame_prof(h, 0, n, true); pr != VOFOD_OK)
             return pr;
         ws.closefar_fused = mapclose != nullptr;
         HIPCHK(hipGetLastError());
@@ -2180,9 +2233,23 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   {
     HIPCHK(hipEventSynchronize(ws.ev_done));
     ws.pending = false;
+    if (ws.prof_deferred && h->d_prof_ccl)
+    {
+      ws.prof_deferred = false;
+      if (const int pr = print_frame_prof(h, ws.prof_slot0, n, false); pr != VOFOD_OK)
+        return pr;
+    }
   }
   else
+  {
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (ws.prof_deferred && h->d_prof_ccl)
+    {
+      ws.prof_deferred = false;
+      if (const int pr = print_frame_prof(h, ws.prof_slot0, n, false); pr != VOFOD_OK)
+        return pr;
+    }
+  }
   tr_sync1 = ms_since(t0);
   if (ws.lite)
     for (uint32_t f = 0; f < n; f++)
