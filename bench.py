@@ -536,15 +536,11 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F, V_far=0.0):
     alg = {
         # batched fast path (kernels_frame.h)
         "k_bbox": 12.0 * n_pts * F,          # bounding box: one read of the xyz columns
-        "k_key1<true>": 12.0 * n_pts * F,    # single pass over the xyz columns: bounding box + reference cells
-        "k_key1<false>": 12.0 * n_pts * F,
-        "k_key2<true>": 12.0 * n_pts * F,    # brick codes: the second read of the same columns (counted again here, once in the path total)
-        "k_key2<false>": 12.0 * n_pts * F,
-        "k_frame_lds_full<false>": 40.0 * V * F,  # weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
-        "k_frame_lds_full<true>": 40.0 * V * F,
+        # round 5: the frame kernel reads the xyz columns itself (one pass: 12*N) ...
+        "k_frame_lds_full": (12.0 * n_pts + 40.0 * V) * F,  # ... weighted cloud out 16*V, clustering in 16*V, labels 4*V, member list 4*V
         # close first (round 4): the weighted cloud out 16*V, one bit of the dilated map image per voxel, and the clustering's
         # 16 + 4 + 4 bytes only for the voxels of the far clusters - what this kernel HAS to move, not the contract's 40*V
-        "k_frame_lds_far": (16.0 * V + V / 8.0 + 24.0 * V_far) * F,
+        "k_frame_lds_far": (12.0 * n_pts + 16.0 * V + V / 8.0 + 24.0 * V_far) * F,
         # general path (single scans, fallbacks)
         "k_setbits": 12.0 * n_pts * F,
         "k_key": 12.0 * n_pts * F,

@@ -64,12 +64,12 @@ def _compare_far_views(ref, dev, scans, tfs, chunk=32, clusters_cap=8192):
                 raise AssertionError(f"far view, frame {f0 + k}: {e}") from e
 
 
-@pytest.mark.parametrize("fallback", ["", "VOFOD_CLOSE_FIRST=0", "VOFOD_DEVICE_TAIL=0", "VOFOD_ONEPASS=0", "VOFOD_LDS_MAX_BRICKS=4096"])
+@pytest.mark.parametrize("fallback", ["", "VOFOD_CLOSE_FIRST=0", "VOFOD_DEVICE_TAIL=0", "VOFOD_LDS_MAX_BRICKS=4096"])
 def test_bench_workload_256_frames_os1_128(oracle, hip, fallback, monkeypatch):
     """configs[3] on one GPU = the bench.py default: 256 x OS1-128 @ 0.25 m, the warmed map, vofod_batch_submit/collect
-    (k_key1 -> k_frame_lds_far -> k_tail_far), every frame against the oracle - by default and under each production fallback:
-    the full clustering (what a cold map takes), the host tail (what a capacity of the device tail falls back to), the two-pass
-    input, and frames beyond the LDS image (every frame here holds more than 4096 bricks: the batch is run again on the
+    (k_frame_lds_far, which reads the input itself, -> k_tail_far), every frame against the oracle - by default and under each production fallback:
+    the full clustering (what a cold map takes), the host tail (what a capacity of the device tail falls back to), and frames
+    beyond the LDS image (every frame here holds more than 4096 bricks: the batch is run again on the
     global-memory kernels).  The switches are read on every call (vofod_hip.hip switch_off)."""
     if fallback:
         k, v = fallback.split("=")
@@ -93,9 +93,9 @@ def test_bench_workload_256_frames_os1_128(oracle, hip, fallback, monkeypatch):
     names = _profiled_kernels(dev.lib, dev)
     dev.lib.profile_enable(dev.h, 0)
     if not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK"):
-        expect = {"": "k_frame_lds_far", "VOFOD_CLOSE_FIRST=0": "k_frame_lds_full", "VOFOD_DEVICE_TAIL=0": "k_pack_lite", "VOFOD_ONEPASS=0": "k_key2<true>", "VOFOD_LDS_MAX_BRICKS=4096": "k_brick_root"}[fallback]
+        expect = {"": "k_frame_lds_far", "VOFOD_CLOSE_FIRST=0": "k_frame_lds_full", "VOFOD_DEVICE_TAIL=0": "k_pack_lite", "VOFOD_LDS_MAX_BRICKS=4096": "k_brick_root"}[fallback]
         assert expect in names, (fallback, names)
-        if fallback in ("", "VOFOD_ONEPASS=0"):
+        if fallback == "":
             assert "k_tail_far" in names, names
     # (the calls without debug output read back the lite slots - candidate clusters only; the debug call above the full tables)
     np.testing.assert_array_equal(want[0]["n_points"], db_full["n_points"])
@@ -468,7 +468,7 @@ def test_voxels_as_pc_debug_clouds(oracle, hip):
 
 @pytest.mark.parametrize("voxel_size", [0.25, 0.1])
 def test_single_pass_input_points_on_cell_boundaries(oracle, hip, voxel_size):
-    """k_key1 reads the input once and encodes the survivors in a reference lattice; points within a rounding band of a
+    """The frame kernel reads the input once and encodes the survivors in a reference lattice; points within a rounding band of a
     cell boundary are re-encoded with the frame's own offset.  Frames full of points a few ulps around cell boundaries
     (of the reference lattice and of the frame's own), with different bounding boxes per frame, against the oracle."""
     sensor = "os1-16"

@@ -320,7 +320,7 @@ def test_no_map_update_and_batch_parity(oracle, hip):
 
 def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, monkeypatch):
     """0.25 m voxels, tolerance 1.5 m: bricks are cliques, batches of >= 4 frames are voxelised and clustered inside LDS
-    (k_key1 -> k_frame_lds); a frame with more bricks than the kernel takes makes the host run the batch again on the
+    (k_frame_lds); a frame with more bricks than the kernel takes makes the host run the batch again on the
     general kernels (slab voxeliser + global-memory brick clustering)."""
     scene = synth.make_scene(41, n_targets=3)
     scans = synth.scan_sequence(scene, "os1-128", 6, seed0=700)
@@ -354,7 +354,7 @@ def test_lds_brick_clustering_in_batches_and_its_overflow_fallback(oracle, hip, 
 
 @pytest.mark.parametrize("voxel_size", [0.25, 0.5])
 def test_large_batch_takes_the_fused_slab_emission(oracle, hip, voxel_size):
-    """>= 128 frames per batch.  0.25 m: bricks are cliques -> the frame kernel (k_key1 -> k_frame_lds); 0.5 m: voxel-level
+    """>= 128 frames per batch.  0.25 m: bricks are cliques -> the frame kernel (k_frame_lds); 0.5 m: voxel-level
     clustering -> the general path, whose large-batch form is k_slab_emit (bitmap slab in LDS -> voxel records, instead of
     k_slab + k_scan_b + k_emit) followed by k_union<2> (which reads the whole prefix array)"""
     ref, dev = make_pair(oracle, hip, "os1-16", voxel_size, max_batch=136)

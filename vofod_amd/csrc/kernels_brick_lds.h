@@ -82,9 +82,10 @@ __device__ __forceinline__ bool lb_octtest(unsigned long long m, uint32_t A8, ui
 __device__ __forceinline__ uint32_t lb_shift(uint32_t m, int sh) { return sh >= 0 ? (sh < 32 ? m >> sh : 0u) : m << (-sh); }
 
 // Exact test of two occupied bricks, LDS and registers only: x-rows of A against x-rows of B through the ball tables.
-// (ddx,ddy,ddz): brick offset of B from A = (bx,by,bz).
-__device__ __forceinline__ bool lb_pair_conn(const LbTables& tab, const GridParams& g, const BrickParams& bp, const FrameHdr& h, unsigned long long A, unsigned long long B, int bx,
-                                             int by, int bz, int ddx, int ddy, int ddz)
+// (cx,cy,cz): cell of brick A's corner in the frame's own lattice (round 5: the bricks are anchored in the batch's reference
+// lattice, a whole-cell shift away); (ddx,ddy,ddz): brick offset of B from A.
+__device__ __forceinline__ bool lb_pair_conn(const LbTables& tab, const GridParams& g, const BrickParams& bp, const FrameHdr& h, unsigned long long A, unsigned long long B, int cx,
+                                             int cy, int cz, int ddx, int ddy, int ddz)
 {
   unsigned long long a = A;
   while (a)
@@ -120,10 +121,10 @@ __device__ __forceinline__ bool lb_pair_conn(const LbTables& tab, const GridPara
         return true;
       if (Ta & b4)
       {
-        const float pyc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + py), 0.5f), g.leaf[1]), h.offset[1]);
-        const float pzc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + pz), 0.5f), g.leaf[2]), h.offset[2]);
-        const float qyc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * (by + ddy) + qy), 0.5f), g.leaf[1]), h.offset[1]);
-        const float qzc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * (bz + ddz) + qz), 0.5f), g.leaf[2]), h.offset[2]);
+        const float pyc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cy + py), 0.5f), g.leaf[1]), h.offset[1]);
+        const float pzc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cz + pz), 0.5f), g.leaf[2]), h.offset[2]);
+        const float qyc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cy + 4 * ddy + qy), 0.5f), g.leaf[1]), h.offset[1]);
+        const float qzc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cz + 4 * ddz + qz), 0.5f), g.leaf[2]), h.offset[2]);
         // (rare path - boundary cases of the tolerance only: kept rolled, it set the kernel's register peak when unrolled)
 #pragma unroll 1
         for (int px = 0; px < 4; px++)
@@ -135,8 +136,8 @@ __device__ __forceinline__ bool lb_pair_conn(const LbTables& tab, const GridPara
             const int bit = 4 * ddx + qx - px + LB_RV;
             if (bit < 0 || bit > 2 * LB_RV || !((Ma >> bit) & 1u))
               continue;
-            const float pxc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + px), 0.5f), g.leaf[0]), h.offset[0]);
-            const float qxc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * (bx + ddx) + qx), 0.5f), g.leaf[0]), h.offset[0]);
+            const float pxc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cx + px), 0.5f), g.leaf[0]), h.offset[0]);
+            const float qxc = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cx + 4 * ddx + qx), 0.5f), g.leaf[0]), h.offset[0]);
             const float ex = __fsub_rn(pxc, qxc), ey = __fsub_rn(pyc, qyc), ez = __fsub_rn(pzc, qzc);
             float d2 = __fmul_rn(ex, ex);
             d2 = __fadd_rn(d2, __fmul_rn(ey, ey));

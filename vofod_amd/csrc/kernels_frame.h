@@ -48,6 +48,10 @@ constexpr uint32_t FR_ROWS_MAX = 8192;    // brick rows (nby * nbz) the per-fram
 constexpr uint32_t FR_CODE_NONE = 0xffffffffu;
 constexpr int FR_BB64 = FR_BW64 + 2 + FR_BW64 / 4;  // 64-bit words of the bitmap (+ 2 guard words) followed by its 16-bit prefix array
 constexpr uint32_t FR_CNT_CAP = FR_BB64 * 8;       // per-voxel byte counters that fit the same storage
+#ifndef FR_REG_ROUNDS_DEF
+#define FR_REG_ROUNDS_DEF 3
+#endif
+constexpr int FR_REG_ROUNDS = FR_REG_ROUNDS_DEF;  // rounds (1 024 codes) of a wave's code segment that stay in registers between the passes 3a and 3b
 constexpr int CF_MAX = FR_THREADS;                 // close-first clustering: pure-far bricks per frame (one per thread); a frame with more takes the full clustering
 #ifndef CF_G_DEF
 #define CF_G_DEF 4
@@ -59,11 +63,14 @@ constexpr uint32_t CF_LABEL_NONE = 0xffffffffu;    // label of a voxel outside t
 struct FrameScratch
 {
   unsigned long long* rowT;  // [F][FR_ROWS_MAX][4]: per brick row, per zz: the four yy channel totals, 16 bits each
-  uint32_t* rowQ;            // [F][FR_ROWS_MAX][4]: rank of the first voxel of lattice rows (4 bz + zz, 4 by .. 4 by + 3)
+  uint32_t* rowQ;            // [F][FR_ROWS_MAX][4]: per brick row and zz: voxels of layer zz in the brick rows before it in node order (the rank of the
+                             //   row group's first voxel = this + the slab's constant, k_frame_lds pass c)
   uint32_t* bmin;            // [F][LB_MAX]: per node, the rank of the brick's first voxel
   unsigned long long* bbsave; // [F][FR_BB64]: the brick bitmap + prefix, parked while their LDS holds the per-voxel point counters
   unsigned long long* nodeA; // [F][LB_MAX][4]: per node, per zz: voxels of the earlier bricks of its brick row, per yy channel (16 bits each);
                              //   bit 63 of [3]: the row began inside the node's 64-node chunk (no carry to add)
+  float4* frag;              // [F][pt_cap]: the fragile points of the input pass: transformed coordinates, w: their brick code (written once the frame's lattice is known)
+  uint32_t keys_cap;         // words of a frame's code list (SlabArrays::keys): the point capacity rounded up to IN_SEG_ALIGN - 16 per-wave segments
 };
 
 // 16-byte load through the global address space (the column pointers come out of a struct in memory: the compiler would
@@ -75,136 +82,35 @@ __device__ __forceinline__ float4 ldg_f4(const char* p)
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// ---- K1-K5a in one pass: brick codes of the surviving points ---------------------------------------------------
-constexpr int KEY2_THREADS = 256;
-constexpr int KEY2_PPT = 8;  // consecutive points per thread
-
-template <bool PACKED>
-__global__ __launch_bounds__(KEY2_THREADS) void k_key2(const FrameArgs* args, const GridParams g, const FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap)
-{
-  uint32_t FRAME, BX, GX;
-  if (!frame_block(g, FRAME, BX, GX))
-    return;
-  (void)GX;
-  const FrameArgs& a = args[FRAME];
-  const FrameHdr& h = hdrs[FRAME];
-  if (h.n_in == 0)
-    return;
-  const uint32_t base_blk = BX * KEY2_THREADS * KEY2_PPT;
-  if (base_blk >= a.n)
-    return;
-  const uint32_t i0 = base_blk + threadIdx.x * KEY2_PPT;
-  float px[KEY2_PPT], py[KEY2_PPT], pz[KEY2_PPT];
-  if (PACKED && i0 + KEY2_PPT <= a.n)
-  {
-    // packed float columns, 16-byte aligned: two 16-byte loads per column and thread
-    const float4* cx = reinterpret_cast<const float4*>(a.x + static_cast<uint64_t>(i0) * 4);
-    const float4* cy = reinterpret_cast<const float4*>(a.y + static_cast<uint64_t>(i0) * 4);
-    const float4* cz = reinterpret_cast<const float4*>(a.z + static_cast<uint64_t>(i0) * 4);
-    const float4 x0 = cx[0], x1 = cx[1], y0 = cy[0], y1 = cy[1], z0 = cz[0], z1 = cz[1];
-    px[0] = x0.x, px[1] = x0.y, px[2] = x0.z, px[3] = x0.w, px[4] = x1.x, px[5] = x1.y, px[6] = x1.z, px[7] = x1.w;
-    py[0] = y0.x, py[1] = y0.y, py[2] = y0.z, py[3] = y0.w, py[4] = y1.x, py[5] = y1.y, py[6] = y1.z, py[7] = y1.w;
-    pz[0] = z0.x, pz[1] = z0.y, pz[2] = z0.z, pz[3] = z0.w, pz[4] = z1.x, pz[5] = z1.y, pz[6] = z1.z, pz[7] = z1.w;
-  }
-  else
-  {
-#pragma unroll
-    for (int j = 0; j < KEY2_PPT; j++)
-    {
-      const uint32_t i = i0 + j;
-      const bool ok = i < a.n;
-      px[j] = ok ? ldf(a.x, a.stride, i) : 0.0f;  // (0,0,0) lies inside the exclude box; the index test below drops it anyway
-      py[j] = ok ? ldf(a.y, a.stride, i) : 0.0f;
-      pz[j] = ok ? ldf(a.z, a.stride, i) : 0.0f;
-    }
-  }
-  const int dx = h.div_b[0], dy = h.div_b[1], dz = h.div_b[2];
-  uint32_t code[KEY2_PPT];
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int j = 0; j < KEY2_PPT; j++)
-  {
-    code[j] = FR_CODE_NONE;
-    const float p0 = px[j], p1 = py[j], p2 = pz[j];
-    bool keep = i0 + j < a.n && isfinite(p0) && isfinite(p1) && isfinite(p2);
-    keep = keep && (p0 < g.ex_min[0] || p1 < g.ex_min[1] || p2 < g.ex_min[2] || p0 > g.ex_max[0] || p1 > g.ex_max[1] || p2 > g.ex_max[2]);
-    float q[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
-      q[r] = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
-    keep = keep && !(q[0] < g.op_min[0] || q[1] < g.op_min[1] || q[2] < g.op_min[2] || q[0] > g.op_max[0] || q[1] > g.op_max[1] || q[2] > g.op_max[2]);
-    if (keep)
-    {
-      int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], h.offset[0]), g.inv[0])));
-      int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], h.offset[1]), g.inv[1])));
-      int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], h.offset[2]), g.inv[2])));
-      bool ok = true;
-      if (k0 < 0 || k0 >= dx || k1 < 0 || k1 >= dy || k2 < 0 || k2 >= dz)
-      {
-        // a rounding artefact outside the lattice: the reference aliases it through the linear index
-        // (voxel_grid_weighted.cpp:137); k_key / k_setbits do the same and drop what leaves the index range
-        const uint32_t key = static_cast<uint32_t>(k0 + k1 * dx + k2 * dx * dy);
-        ok = key < h.n_cells;
-        if (ok)
-          key_to_ijk(h, key, k0, k1, k2);
-      }
-      if (ok)
-        code[j] = ((static_cast<uint32_t>(k0 >> 2) | (static_cast<uint32_t>(k1 >> 2) << 9) | (static_cast<uint32_t>(k2 >> 2) << 18)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));  // as cell_code of k_frame_lds
-    }
-    cnt += code[j] != FR_CODE_NONE;
-  }
-  // order-preserving block compaction, one global atomic per 2048 points
-  __shared__ uint32_t s_wsum[KEY2_THREADS / 64];
-  __shared__ uint32_t s_base;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t incl = wave_incl_scan(cnt);
-  if (lane == 63)
-    s_wsum[wave] = incl;
-  __syncthreads();
-  uint32_t off = incl - cnt, total = 0;
-#pragma unroll
-  for (int w = 0; w < KEY2_THREADS / 64; w++)
-  {
-    const uint32_t x = s_wsum[w];
-    off += w < wave ? x : 0u;
-    total += x;
-  }
-  if (threadIdx.x == 0)
-    s_base = total ? atomicAdd(&sa.counts[2 * FRAME], total) : 0u;
-  __syncthreads();
-  uint32_t* out = sa.keys + static_cast<size_t>(FRAME) * pt_cap + s_base + off;
-#pragma unroll
-  for (int j = 0; j < KEY2_PPT; j++)
-    if (code[j] != FR_CODE_NONE)
-      *out++ = code[j];
-}
-
-// ---- one pass over the input instead of two ------------------------------------------------------------------------
+// ---- one pass over the input ---------------------------------------------------------------------------------------
 // The lattice of a frame hangs on its own bounding box (voxel_grid_weighted.cpp:72-106: offset = floor(min * inv) * leaf -
-// align offset), so the cell of a point is only known once every point has been seen: k_bbox + k_key2 read the columns
-// twice.  All such lattices are translates of each other by whole cells - up to float rounding.  k_key1 therefore reads the
-// input ONCE: bounding box as k_bbox, and every survivor's cell in a *reference* lattice anchored at the operation area's
-// corner (the same expressions with the reference offset).  k_frame_lds shifts the reference cells by the integer
-// difference of the two offsets.  A point whose reference position lies within `eps` cells of a cell boundary could land
-// in another cell under the frame's own offset (the float subtraction / product round differently): such *fragile* points
-// (a fraction of a percent) are kept aside by their index in the cloud and encoded later with the exact
-// expression of the reference.  eps is a bound on all rounding differences (see fill_ref_lattice), far above them.
+// align offset), so the cell of a point is only known once every point has been seen.  All such lattices are translates of each
+// other by whole cells - up to float rounding.  The input is therefore read ONCE (round 5: by the frame kernel itself, as its
+// first phase; rounds 2-4 had a streaming kernel k_key1 in front): bounding box, and every survivor's cell in a *reference*
+// lattice anchored at the operation area's corner (the same expressions with the reference offset).  The 4x4x4 bricks the
+// frame kernel works on are bricks of THAT lattice (round 5), so a survivor's brick is known the moment the point is read and the
+// brick bitmap is built while the input streams in; the frame's own lattice only enters as a whole-cell shift where cells leave
+// the kernel (centres, keys, lattice boxes, map cells).  A point whose reference position lies within `eps` cells of a cell
+// boundary could land in another cell under the frame's own offset (the float subtraction / product round differently): such
+// *fragile* points (a fraction of a percent) are kept aside with their transformed coordinates and encoded with the exact
+// expression of the reference once the bounding box is known.  eps is a bound on all rounding differences (see
+// fill_ref_lattice), far above them.
 struct RefLattice
 {
   float off[3];     // reference offset: fl(fl(min_b_ref * leaf) - aco), as voxel_grid_weighted.cpp:80-100 would compute it
   float eps;        // fragile band around cell boundaries, in cells
-  int32_t dims[3];  // reference cells per axis (<= 2048, 2048, 1024: packed 11 + 11 + 10 bits)
+  int32_t dims[3];  // reference cells per axis
+  int32_t nb[3];    // bricks per axis: ceil(dims / 4), at most 512 x 512 x 64 and LB_BITWORDS * 32 in all (the LDS bitmap)
   int32_t on;
 };
 
-#ifndef KEY1_THREADS_DEF
-#define KEY1_THREADS_DEF 256
+#ifndef FR_IN_PREFETCH
+#define FR_IN_PREFETCH 0
 #endif
-constexpr int KEY1_THREADS = KEY1_THREADS_DEF;  // threads per workgroup of k_key1
-#ifndef KEY1_PPT_DEF
-#define KEY1_PPT_DEF 8
-#endif
-constexpr int KEY1_PPT = KEY1_PPT_DEF;  // consecutive points per thread of k_key1 (a multiple of 4)
+constexpr int IN_PPT = 8;                                  // consecutive points per thread and round of the input pass
+constexpr uint32_t IN_ROUND = FR_THREADS * IN_PPT;         // points per round and workgroup
+constexpr uint32_t IN_SEG_ALIGN = 16u * 64u * IN_PPT;      // the code list of a frame: 16 per-wave segments, each a whole number of rounds
+
 // v_min3_f32 / v_max3_f32: two new points per instruction.  A quiet NaN operand is ignored (the other operands decide), which
 // makes qNaN the neutral element of both: dropped points are replaced by it once and need no second select.
 __device__ __forceinline__ float min3_raw(float a, float b, float c)
@@ -294,226 +200,6 @@ __device__ __forceinline__ f32x2 pk_add_s(float c, f32x2 v)
   const unsigned long long c64 = __float_as_uint(c);
   asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(c64), "v"(v));
   return d;
-}
-
-// Round 3: the kernel was bound by its vector instructions (~112 executed per point).  Now: the transform and the cell
-// expression work on PAIRS of consecutive points as packed-f32 operations (v_pk_mul_f32 / v_pk_add_f32: every lane of a
-// packed instruction rounds like the scalar one, so the separately rounded se3 association is kept); the bounding box is
-// two v_min3 / v_max3 per axis and pair with qNaN standing in for dropped points; a point is "solid" when
-// max(|fr - 0.5|) over the axes stays below 0.5 - eps (one v_max3 with |.| modifiers instead of three interval tests).
-template <bool PACKED>
-__global__ __launch_bounds__(KEY1_THREADS) void k_key1(const FrameArgs* __restrict__ args, const GridParams g, FrameHdr* __restrict__ hdrs, SlabArrays sa, uint32_t pt_cap, const RefLattice rl)
-{
-#pragma clang fp contract(off)
-  // (2-D grid: blockIdx.y = frame - the frame / block split of a 1-D grid costs two integer divisions per wave, ~7 % of this
-  // kernel's vector instructions)
-  const uint32_t FRAME = blockIdx.y, BX = blockIdx.x;
-  const FrameArgs a = args[FRAME];  // (a copy: the transform stays in scalar registers)
-  const uint32_t base_blk = BX * KEY1_THREADS * KEY1_PPT;
-  if (base_blk >= a.n)
-    return;
-  const uint32_t i0 = base_blk + threadIdx.x * KEY1_PPT;
-  float px[KEY1_PPT], py[KEY1_PPT], pz[KEY1_PPT];
-  if constexpr (PACKED)
-  {
-    // packed float columns, 16-byte aligned, the number of points a multiple of 4 (the host checks): whole 16-byte loads
-    // only, no strided path in this instantiation (its 64-bit address arithmetic costs registers the packed path never uses)
-#pragma unroll
-    for (int q = 0; q < KEY1_PPT / 4; q++)
-    {
-      // (a quad behind the cloud's end reads the last quad instead - the number of points is a multiple of 4, and at least 4
-      // here; the index test below drops its points: no conditional load, no registers to clear first)
-      const uint64_t o = static_cast<uint64_t>(min(i0 + 4u * q, a.n - 4u)) * 4;
-      const float4 x0 = ldg_f4(a.x + o), y0 = ldg_f4(a.y + o), z0 = ldg_f4(a.z + o);
-      px[4 * q] = x0.x, px[4 * q + 1] = x0.y, px[4 * q + 2] = x0.z, px[4 * q + 3] = x0.w;
-      py[4 * q] = y0.x, py[4 * q + 1] = y0.y, py[4 * q + 2] = y0.z, py[4 * q + 3] = y0.w;
-      pz[4 * q] = z0.x, pz[4 * q + 1] = z0.y, pz[4 * q + 2] = z0.z, pz[4 * q + 3] = z0.w;
-    }
-  }
-  else
-  {
-#pragma unroll
-    for (int j = 0; j < KEY1_PPT; j++)
-    {
-      const uint32_t i = i0 + j;
-      const bool ok = i < a.n;
-      px[j] = ok ? ldf(a.x, a.stride, i) : 0.0f;
-      py[j] = ok ? ldf(a.y, a.stride, i) : 0.0f;
-      pz[j] = ok ? ldf(a.z, a.stride, i) : 0.0f;
-    }
-  }
-  float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  uint32_t code[KEY1_PPT];
-  uint32_t cnt = 0, frag_mask = 0;
-  uint32_t* frag = sa.extras + static_cast<size_t>(FRAME) * pt_cap;  // fragile points: their transformed coordinates, 3 floats each
-  float sq0 = 0.0f, sq1 = 0.0f, sq2 = 0.0f;  // ... of the thread's FIRST fragile point (8 % of the threads have one, 0.3 % a second)
-  // Branch-free per point: a value lies inside a closed interval iff the median of (value, low, high) is the value itself -
-  // one v_med3 + one compare per axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed
-  // point, which fails the operation-area test: the explicit isfinite() of the first crop is implied.
-  auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
-  // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop)
-  float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-    asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
-  const float solid_lim = 0.5f - rl.eps;
-  const float qnan = __int_as_float(0x7fc00000);
-#pragma unroll
-  for (int jp = 0; jp < KEY1_PPT / 2; jp++)
-  {
-    const int j0 = 2 * jp, j1 = 2 * jp + 1;
-    const f32x2 X = {px[j0], px[j1]}, Y = {py[j0], py[j1]}, Z = {pz[j0], pz[j1]};
-    bool in_ex[2], in_op[2], keep[2];
-#pragma unroll
-    for (int e = 0; e < 2; e++)
-      in_ex[e] = static_cast<int>(inside(X[e], g.ex_min[0], ex_hi[0])) & inside(Y[e], g.ex_min[1], ex_hi[1]) & inside(Z[e], g.ex_min[2], ex_hi[2]);
-    f32x2 q[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
-      q[r] = pk_mul_s(a.tf[4 * r + 0], X) + (pk_mul_s(a.tf[4 * r + 1], Y) + pk_add_s(a.tf[4 * r + 3], pk_mul_s(a.tf[4 * r + 2], Z)));
-#pragma unroll
-    for (int e = 0; e < 2; e++)
-    {
-      in_op[e] = static_cast<int>(inside(q[0][e], g.op_min[0], op_hi[0])) & inside(q[1][e], g.op_min[1], op_hi[1]) & inside(q[2][e], g.op_min[2], op_hi[2]);
-      keep[e] = (i0 + j0 + e < a.n) & !in_ex[e] & in_op[e];
-    }
-    code[j0] = code[j1] = FR_CODE_NONE;
-    if (!__any(keep[0] | keep[1]))
-      continue;  // (wave-uniform) 128 dropped points: whole rings look at the sky
-    // pcl::getMinMax3D (voxel_grid_weighted.cpp:58) over the kept points
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-    {
-      const float m0 = keep[0] ? q[c][0] : qnan, m1 = keep[1] ? q[c][1] : qnan;
-      fmn[c] = min3_raw(fmn[c], m0, m1);
-      fmx[c] = max3_raw(fmx[c], m0, m1);
-    }
-    // reference cell (voxel_grid_weighted.cpp:131-136 with the reference offset) and the distance from the cell's middle
-    f32x2 fl[3], gmid[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-    {
-      const f32x2 t = pk_mul_s(g.inv[c], pk_add_s(-rl.off[c], q[c]));  // (q - off) * inv: adding the negated offset rounds as the subtraction does
-      fl[c][0] = floorf(t[0]);
-      fl[c][1] = floorf(t[1]);
-      const f32x2 half = {0.5f, 0.5f};
-      gmid[c] = t - (fl[c] + half);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; e++)
-    {
-      const uint32_t k0 = static_cast<uint32_t>(static_cast<int>(fl[0][e])), k1 = static_cast<uint32_t>(static_cast<int>(fl[1][e])), k2 = static_cast<uint32_t>(static_cast<int>(fl[2][e]));
-      // (negative or huge cells set bits above the fields: one test for all three; a kept point lies inside the operation
-      // area, whose cells the reference lattice covers - the test only guards the packing)
-      const bool fits = (k0 | k1 | (k2 << 1)) < 2048u;
-      const bool solid = keep[e] & fits & (max3_abs(gmid[0][e], gmid[1][e], gmid[2][e]) <= solid_lim);
-      cnt += solid ? 1u : 0u;
-      code[j0 + e] = solid ? (k0 | (k1 << 11) | (k2 << 22)) : FR_CODE_NONE;
-      const bool fragile = keep[e] & !solid;  // kept aside with its transformed coordinates: k_frame_lds encodes it with the frame's own offset
-      const bool first_fr = fragile & (frag_mask == 0u);
-      sq0 = first_fr ? q[0][e] : sq0;
-      sq1 = first_fr ? q[1][e] : sq1;
-      sq2 = first_fr ? q[2][e] : sq2;
-      frag_mask |= fragile ? (1u << (j0 + e)) : 0u;
-    }
-  }
-  // bounding box of the block ...
-  const bool any_kept = (cnt | frag_mask) != 0u;
-  int mn[3], mx[3];
-  wave_bbox(fmn, fmx);
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-  {
-    // (+-inf where the wave kept nothing: the ordered form of +inf / -inf is the identity of the integer atomics below)
-    mn[c] = f2ord(fmn[c]);
-    mx[c] = f2ord(fmx[c]);
-  }
-  (void)any_kept;
-  __shared__ int s_red[KEY1_THREADS / 64][6];
-  __shared__ uint32_t s_wsum[KEY1_THREADS / 64], s_fsum[KEY1_THREADS / 64];
-  __shared__ uint32_t s_base, s_fbase;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t incl = wave_incl_scan(cnt);
-  const uint32_t fcnt = __popc(frag_mask), fincl = wave_incl_scan(fcnt);
-  if (lane == 63)
-  {
-    s_wsum[wave] = incl;
-    s_fsum[wave] = fincl;
-  }
-  if (lane == 0)
-  {
-    for (int c = 0; c < 3; c++)
-    {
-      s_red[wave][c] = mn[c];
-      s_red[wave][3 + c] = mx[c];
-    }
-  }
-  __syncthreads();
-  uint32_t off = incl - cnt, total = 0, foff = fincl - fcnt, ftotal = 0;
-#pragma unroll
-  for (int w = 0; w < KEY1_THREADS / 64; w++)
-  {
-    const uint32_t x = s_wsum[w], y = s_fsum[w];
-    off += w < wave ? x : 0u;
-    total += x;
-    foff += w < wave ? y : 0u;
-    ftotal += y;
-  }
-  if (threadIdx.x == 0)
-  {
-    // one returning atomic reserves both lists: the two counters of a frame share a 64-bit word
-    const unsigned long long both =
-        (total | ftotal) ? atomicAdd(reinterpret_cast<unsigned long long*>(&sa.counts[2 * FRAME]), static_cast<unsigned long long>(total) | (static_cast<unsigned long long>(ftotal) << 32)) : 0ull;
-    s_base = static_cast<uint32_t>(both);
-    s_fbase = static_cast<uint32_t>(both >> 32);
-    if (total | ftotal)
-    {
-      for (int w = 0; w < KEY1_THREADS / 64; w++)
-        for (int c = 0; c < 3; c++)
-        {
-          mn[c] = min(mn[c], s_red[w][c]);
-          mx[c] = max(mx[c], s_red[w][3 + c]);
-        }
-      FrameHdr& h = hdrs[FRAME];
-      atomicAdd(&h.n_in, total + ftotal);
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-      {
-        atomicMin(&h.bb_min[c], mn[c]);
-        atomicMax(&h.bb_max[c], mx[c]);
-      }
-    }
-  }
-  __syncthreads();
-  // ... and the reference cells of its (non-fragile) survivors, in point order
-  uint32_t* out = sa.keys + static_cast<size_t>(FRAME) * pt_cap + s_base + off;
-#pragma unroll
-  for (int j = 0; j < KEY1_PPT; j++)
-    if (code[j] != FR_CODE_NONE)
-      *out++ = code[j];
-  if (frag_mask)
-  {
-    // A fragile point leaves as its transformed coordinates (12 bytes), not as its index (round 3): the frame kernel then
-    // fetched x, y, z from the input columns again - ~550 random 4-byte reads per frame and column, 430 k random 64-byte DRAM
-    // accesses per batch at the moment all 256 workgroups start: 10-15 us at the head of every frame's critical path (measured:
-    // the same loop on sequential or cache-resident indices takes 2-3 us).  The first fragile point of a thread was kept in
-    // registers; a further one (0.3 % of the threads) is loaded again - its line is still in the cache - and transformed with the
-    // very expression of the loop above (packed or not, every operation rounds the same).
-    float* fout = reinterpret_cast<float*>(frag) + 3u * (s_fbase + foff);
-    fout[0] = sq0, fout[1] = sq1, fout[2] = sq2;
-    fout += 3;
-    uint32_t rest = frag_mask & (frag_mask - 1u);
-    while (rest)
-    {
-      const uint32_t pi = i0 + static_cast<uint32_t>(__ffs(static_cast<int>(rest)) - 1);
-      rest &= rest - 1u;
-      const uint64_t st = PACKED ? 4u : a.stride;
-      const float p0 = ldf(a.x, st, pi), p1 = ldf(a.y, st, pi), p2 = ldf(a.z, st, pi);
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-        *fout++ = __fadd_rn(__fmul_rn(a.tf[4 * r + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * r + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * r + 2], p2), a.tf[4 * r + 3])));
-    }
-  }
 }
 
 // ---- helpers of k_frame_lds ----------------------------------------------------------------------------------------
@@ -647,7 +333,9 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
 // pure-far bricks (see behind phase 3a) and the full clustering's code is not in the kernel at all (it set the register
 // budget); a frame beyond its capacity raises CF_RETRY_STATUS and the host runs the batch again with CFM = 0, the kernel of
 // rounds 2-3.
-template <int CFM>
+// Round 5: the kernel reads the input columns itself (phase "in"); PACKED: every frame of the batch has packed float
+// columns, 16-byte aligned, a multiple of 4 points (the host checks) - 16-byte loads; otherwise strided 4-byte loads.
+template <int CFM, bool PACKED>
 __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
                                                          VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
                                                          const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
@@ -655,6 +343,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
                                                          CandMember* __restrict__ cand_all, int write_tables, unsigned long long* __restrict__ prof, const RefLattice rl, const FrameArgs* __restrict__ args,
                                                          int close_first)
 {
+#pragma clang fp contract(off)
   __shared__ __attribute__((aligned(16))) unsigned long long s_bb[FR_BB64];  // brick-lattice bitmap (bit = linear brick id) + exclusive popcount prefix per
                                                                             // 64-bit word; during the counting / rank phases: one byte counter per voxel
   __shared__ unsigned long long s_word[LB_MAX];                                      // node -> occupancy word; phase E: component minima / statistics
@@ -668,64 +357,50 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   __shared__ uint32_t s_nhn;  // both adjacent-hit counters of the probe: face neighbours << 17 | others (<= 3 and 10 per brick)
   // close-first clustering (round 4, see the block behind phase 3a): the frame's pure-far bricks
   __shared__ uint16_t s_pf[CF_MAX];     // their nodes
-  __shared__ uint16_t s_pfpar[CF_MAX];  // union-find over the list's indices
+  __shared__ __attribute__((aligned(16))) uint16_t s_pfpar[CF_MAX];  // union-find over the list's indices (set up behind the emission; the rank pass c borrows the storage)
   __shared__ uint32_t s_taint[CF_MAX / 32], s_troot[CF_MAX / 32];  // bit k: list entry k has an edge to a brick with a close voxel / the component rooted at k holds such an entry
   __shared__ uint32_t s_npf, s_nc, s_no2, s_ncand;
   __shared__ __attribute__((aligned(16))) uint32_t s_cfd[32][4];  // (stencil row, direction) descriptors of the close-first edge passes
   __shared__ uint8_t s_cfl[2][32];
   __shared__ uint32_t s_cfn[2];
+  // input pass: per-wave results (bounding box as ordered ints, codes appended), the fragile points' counter, the frame's shift
+  __shared__ int s_red[FR_THREADS / 64][6];
+  __shared__ uint32_t s_wcnt[FR_THREADS / 64];
+  __shared__ uint32_t s_nfrag;
+  __shared__ __attribute__((aligned(16))) uint32_t s_qc[FR_MAX_NBZ][4];      // ... and the slabs' constants: row-group base rank = rowQ + s_qc[bz]
+  __shared__ int s_lat[4];      // the frame's own lattice: div_b, n_cells
+  __shared__ float s_latf[3];   // ... and its offset
+  __shared__ int s_shift[4];  // whole cells between the reference lattice and the frame's own: frame cell = reference cell - shift; [3]: the frame is empty / failed
+  // rank pass c (before the emission, while the close-first union-find is not yet in use): G at the first row of every slab (~0: no
+  // brick in the slab; [FR_MAX_NBZ]: totals), and the waves' sums of the block scan
+  static_assert(sizeof(unsigned long long) * (FR_MAX_NBZ + 1 + FR_THREADS / 64) <= sizeof(uint16_t) * CF_MAX, "rank pass c borrows the union-find's storage");
+  unsigned long long* s_gs = reinterpret_cast<unsigned long long*>(s_pfpar);  // (four 16-bit fields: one per lattice layer zz of a slab)
+  unsigned long long* s_w4 = s_gs + FR_MAX_NBZ + 1;
   unsigned long long* s_bits64 = s_bb;
   uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_bb + FR_BW64 + 2);
   uint32_t* s_cnt32 = reinterpret_cast<uint32_t*>(s_bb);
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bits64);
   uint16_t* s_vbase = reinterpret_cast<uint16_t*>(s_x2);  // node -> index of its first voxel in brick order (counting / rank phases)
   uint16_t* s_par = reinterpret_cast<uint16_t*>(s_x2);
-  // the streaming kernels of the next batch run beside this kernel (process_frames' pipeline): this kernel's waves are the
-  // critical path and go first wherever both want to issue
+  // the classification tails of the batches in front run beside this kernel (process_frames' pipeline): this kernel's waves go
+  // first wherever both want to issue
   __builtin_amdgcn_s_setprio(FR_WAVE_PRIO);
   const uint32_t FRAME = blockIdx.x;
-  const uint32_t SRC = FRAME;
   FrameHdr& h = hdrs[FRAME];
-  __shared__ int s_mapk[4];  // lattice cell -> map cell offsets, [3]: valid (see below)
+  __shared__ int s_mapk[4];  // REFERENCE cell -> map cell offsets, [3]: valid (see below)
   __shared__ __attribute__((aligned(16))) uint32_t s_near[5][4];  // descriptors of the stencil rows that hold adjacent bricks (phase D)
   __shared__ uint32_t s_near_n;
-  if (rl.on)
-  {
-    // single-pass input: the frame's lattice (voxel_grid_weighted.cpp:61-113) is set up here, from the bounding box k_key1
-    // left in the header - one kernel less between the streaming kernel and this one (k_grid, a launch gap of the pipeline)
-    if (threadIdx.x == 0)
-    {
-      grid_of_frame(g, h);
-    }
-    __syncthreads();
-  }
-  // single-pass input (k_key1): the list holds reference cells, the fragile points wait beside it with their coordinates
-  const uint32_t n_ref = sa.counts[2 * SRC];
-  const uint32_t n_frag = rl.on ? sa.counts[2 * SRC + 1] : 0u;
-  uint32_t n_keys = n_ref + n_frag;
-  if (h.n_in == 0 || n_keys == 0)
-    return;  // k_init_hdr left V = C = 0
   const VoxelArrays va = frame_voxels(va_all, FRAME, g.vox_cap);
   uint32_t* labels = labels_all + static_cast<size_t>(FRAME) * g.vox_cap;
   uint32_t* s_cmin = reinterpret_cast<uint32_t*>(s_word);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int dx = h.div_b[0], dxy = h.div_b[0] * h.div_b[1];
-  const int nbx = (h.div_b[0] + 3) >> 2, nby = (h.div_b[1] + 3) >> 2, nbz = (h.div_b[2] + 3) >> 2;
+  // the brick lattice: bricks of the reference lattice - the same for every frame of the batch
+  const int nbx = rl.nb[0], nby = rl.nb[1], nbz = rl.nb[2];
   const uint32_t nb_total = static_cast<uint32_t>(nbx) * nby * nbz;
 #define FR_STAMP(i)     \
   if (prof && tid == 0) \
   prof[static_cast<size_t>(FRAME) * 32 + (i)] = wall_clock64()
   FR_STAMP(0);
-  if (static_cast<long long>(nbx) * nby * nbz > static_cast<long long>(LB_BITWORDS) * 32 || nbx > 512 || nby > 512 || nbz > FR_MAX_NBZ ||
-      static_cast<uint32_t>(nby) * nbz > FR_ROWS_MAX)
-  {
-    if (tid == 0)
-    {
-      h.status = CCL_RETRY_STATUS;
-      h.V = 0;  // the frame is empty for the rest of the chain; the host re-runs the batch
-    }
-    return;
-  }
   for (int s = tid; s < FR_BW64 + 2; s += FR_THREADS)
     s_bits64[s] = 0ull;
   for (int s = tid; s < static_cast<int>(sizeof(LbTables) / 4); s += FR_THREADS)
@@ -742,195 +417,411 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     s_nc = 0;
     s_no2 = 0;
     s_ncand = 0;
+    s_nfrag = 0;
   }
   if (tid < CF_MAX / 32)
     s_taint[tid] = s_troot[tid] = 0u;
   __syncthreads();
-  const uint32_t* codes = sa.keys + static_cast<size_t>(FRAME) * pt_cap;      // the list the passes 3a / 3b read
-  const uint32_t* codes_src = sa.keys + static_cast<size_t>(SRC) * pt_cap;    // k_key1's list of the whole frame
+  // bit of a packed brick in the brick bitmap
+  auto brick_lin = [&](uint32_t p) -> uint32_t { return (((p >> 18) & 63u) * static_cast<uint32_t>(nby) + ((p >> 9) & 511u)) * static_cast<uint32_t>(nbx) + (p & 511u); };
+  // brick code of a reference cell: packed brick coordinates (fr_pack), then the bit inside the brick
+  auto ref_cell_code = [](uint32_t k0, uint32_t k1, uint32_t k2) -> uint32_t {
+    return (fr_pack(k0 >> 2, k1 >> 2, k2 >> 2) << 6) | (k0 & 3u) | ((k1 & 3u) << 2) | ((k2 & 3u) << 4);
+  };
+  // ---- in: the input columns, once (vofod_nodelet.cpp:625-655 CropBox, transformPointCloud, CropBox; voxel_grid_weighted.cpp:58
+  // getMinMax3D, :131-136 the cell of a point).  Round r: thread t takes the IN_PPT consecutive points from (r * FR_THREADS + t) *
+  // IN_PPT on; the next round's loads are in flight while a round is worked on.  Survivors away from cell boundaries ("solid")
+  // set their brick's bit in the LDS bitmap at once (one LDS atomic per run of a thread's consecutive points in one brick) and
+  // leave as brick codes in the wave's own segment of the frame's code list, in point order (points of a ring that share a voxel
+  // / brick stay neighbours: the later passes merge such runs in registers); no block-wide step inside the loop.
+  const FrameArgs a = args[FRAME];  // (a copy: pointers and transform stay in scalar registers)
+  const uint32_t n_pts = a.n;
+  const uint32_t keys_cap = fs.keys_cap, seg_cap = fs.keys_cap / (FR_THREADS / 64);
+  uint32_t* seg = sa.keys + static_cast<size_t>(FRAME) * keys_cap + static_cast<size_t>(wave) * seg_cap;
+  float4* fragl = fs.frag + static_cast<size_t>(FRAME) * pt_cap;  // the fragile points: transformed coordinates, then (w) their brick code
+  uint32_t wcnt = 0;  // codes in this wave's segment (wave-uniform)
+  {
+    const uint32_t in_rounds = (n_pts + IN_ROUND - 1u) / IN_ROUND;
+    if (static_cast<uint64_t>(in_rounds) * 64u * IN_PPT > seg_cap)
+    {
+      if (tid == 0)
+      {
+        h.status = VOFOD_ERR_CAPACITY;  // (a cloud beyond the workspace's code list: the host sizes it for the sensor)
+        h.V = 0;
+      }
+      return;
+    }
+    float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // Branch-free per point: a value lies inside a closed interval iff the median of (value, low, high) is the value itself -
+    // one v_med3 + one compare per axis, exact, false for NaN.  A non-finite input can only give a non-finite transformed
+    // point, which fails the operation-area test: the explicit isfinite() of the first crop is implied.
+    auto inside = [](float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; };
+    // (v_med3 reads one scalar register at most: the upper bounds live in vector registers for the whole loop)
+    float ex_hi[3] = {g.ex_max[0], g.ex_max[1], g.ex_max[2]}, op_hi[3] = {g.op_max[0], g.op_max[1], g.op_max[2]};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
+    const float solid_lim = 0.5f - rl.eps;
+    const float qnan = __int_as_float(0x7fc00000);
+    const uint32_t cell_lim = 2048u;  // (k0 | k1 | k2 << 3) < 2048: the cell fits the code's fields (9 + 2, 9 + 2, 6 + 2 bits)
+    auto load_round = [&](uint32_t r, float (&X)[IN_PPT], float (&Y)[IN_PPT], float (&Z)[IN_PPT]) {
+      const uint32_t i0 = r * IN_ROUND + ((static_cast<uint32_t>(wave) + r) & (FR_THREADS / 64 - 1)) * (64u * IN_PPT) + static_cast<uint32_t>(lane) * IN_PPT;
+      if constexpr (PACKED)
+      {
+#pragma unroll
+        for (int q = 0; q < IN_PPT / 4; q++)
+        {
+          // (a quad behind the cloud's end reads the last quad instead - the number of points is a multiple of 4, and at least 4
+          // here; the index test below drops its points: no conditional load, no registers to clear first)
+          const uint64_t o = static_cast<uint64_t>(min(i0 + 4u * q, n_pts - 4u)) * 4;
+          const float4 x0 = ldg_f4(a.x + o), y0 = ldg_f4(a.y + o), z0 = ldg_f4(a.z + o);
+          X[4 * q] = x0.x, X[4 * q + 1] = x0.y, X[4 * q + 2] = x0.z, X[4 * q + 3] = x0.w;
+          Y[4 * q] = y0.x, Y[4 * q + 1] = y0.y, Y[4 * q + 2] = y0.z, Y[4 * q + 3] = y0.w;
+          Z[4 * q] = z0.x, Z[4 * q + 1] = z0.y, Z[4 * q + 2] = z0.z, Z[4 * q + 3] = z0.w;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < IN_PPT; j++)
+        {
+          const uint32_t i = min(i0 + j, n_pts - 1u);  // (clamped: the index test drops it)
+          X[j] = ldf(a.x, a.stride, i);
+          Y[j] = ldf(a.y, a.stride, i);
+          Z[j] = ldf(a.z, a.stride, i);
+        }
+      }
+    };
+#if FR_IN_PREFETCH
+    float cx_[IN_PPT], cy_[IN_PPT], cz_[IN_PPT];
+#endif
+    for (uint32_t r = 0; r < in_rounds; r++)
+    {
+      // (No software prefetch of the next round: the codes' stores sit between a prefetch and its use, conditional stores make the
+      // compiler's vmcnt bookkeeping give up - s_waitcnt vmcnt(0) - and every round then ended with a full drain of its own stores.
+      // Loads issued here, after the previous round's stores, are the youngest operations when they are waited for; the four waves
+      // of a SIMD cover each other's latency.)
+      float px[IN_PPT], py[IN_PPT], pz[IN_PPT];
+#if FR_IN_PREFETCH
+      float nx[IN_PPT], ny[IN_PPT], nz[IN_PPT];
+      if (r == 0)
+        load_round(0, px, py, pz);
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < IN_PPT; j++)
+          px[j] = cx_[j], py[j] = cy_[j], pz[j] = cz_[j];
+      }
+      if (r + 1 < in_rounds)
+        load_round(r + 1, nx, ny, nz);
+#else
+      load_round(r, px, py, pz);
+#endif
+      // (the waves take the round's 512-point pieces in turn: a wave sees every azimuth sector and ring parity - even load)
+      const uint32_t i0 = r * IN_ROUND + ((static_cast<uint32_t>(wave) + r) & (FR_THREADS / 64 - 1)) * (64u * IN_PPT) + static_cast<uint32_t>(lane) * IN_PPT;
+      uint32_t code[IN_PPT];
+      uint32_t cnt = 0, frag_mask = 0;
+      float sq0 = 0.0f, sq1 = 0.0f, sq2 = 0.0f;  // transformed coordinates of the thread's FIRST fragile point of the round (8 % of the threads have one, 0.3 % a second)
+      // the transform and the cell expression work on PAIRS of consecutive points as packed-f32 operations (v_pk_mul_f32 /
+      // v_pk_add_f32: every lane of a packed instruction rounds like the scalar one, so the separately rounded se3 association
+      // is kept); the bounding box is two v_min3 / v_max3 per axis and pair with qNaN standing in for dropped points; a point is
+      // "solid" when max(|fr - 0.5|) over the axes stays below 0.5 - eps (one v_max3 with |.| modifiers)
+#pragma unroll
+      for (int jp = 0; jp < IN_PPT / 2; jp++)
+      {
+        const int j0 = 2 * jp, j1 = 2 * jp + 1;
+        const f32x2 X = {px[j0], px[j1]}, Y = {py[j0], py[j1]}, Z = {pz[j0], pz[j1]};
+        bool in_ex[2], in_op[2], keep[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+          in_ex[e] = static_cast<int>(inside(X[e], g.ex_min[0], ex_hi[0])) & inside(Y[e], g.ex_min[1], ex_hi[1]) & inside(Z[e], g.ex_min[2], ex_hi[2]);
+        f32x2 q[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)  // pcl::detail::Transformer<float>::se3: c0*x + (c1*y + (c2*z + c3)), every op rounded
+          q[rr] = pk_mul_s(a.tf[4 * rr + 0], X) + (pk_mul_s(a.tf[4 * rr + 1], Y) + pk_add_s(a.tf[4 * rr + 3], pk_mul_s(a.tf[4 * rr + 2], Z)));
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+        {
+          in_op[e] = static_cast<int>(inside(q[0][e], g.op_min[0], op_hi[0])) & inside(q[1][e], g.op_min[1], op_hi[1]) & inside(q[2][e], g.op_min[2], op_hi[2]);
+          keep[e] = (i0 + j0 + e < n_pts) & !in_ex[e] & in_op[e];
+        }
+        code[j0] = code[j1] = FR_CODE_NONE;
+        if (!__any(keep[0] | keep[1]))
+          continue;  // (wave-uniform) 128 dropped points: whole rings look at the sky
+        // pcl::getMinMax3D (voxel_grid_weighted.cpp:58) over the kept points
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+        {
+          const float m0 = keep[0] ? q[c][0] : qnan, m1 = keep[1] ? q[c][1] : qnan;
+          fmn[c] = min3_raw(fmn[c], m0, m1);
+          fmx[c] = max3_raw(fmx[c], m0, m1);
+        }
+        // reference cell (voxel_grid_weighted.cpp:131-136 with the reference offset) and the distance from the cell's middle
+        f32x2 fl[3], gmid[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+        {
+          const f32x2 t = pk_mul_s(g.inv[c], pk_add_s(-rl.off[c], q[c]));  // (q - off) * inv: adding the negated offset rounds as the subtraction does
+          fl[c][0] = floorf(t[0]);
+          fl[c][1] = floorf(t[1]);
+          const f32x2 half = {0.5f, 0.5f};
+          gmid[c] = t - (fl[c] + half);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+        {
+          const uint32_t k0 = static_cast<uint32_t>(static_cast<int>(fl[0][e])), k1 = static_cast<uint32_t>(static_cast<int>(fl[1][e])), k2 = static_cast<uint32_t>(static_cast<int>(fl[2][e]));
+          // (negative or huge cells set bits above the fields: one test for all three; a kept point lies inside the operation
+          // area, whose cells the reference lattice covers - the test only guards the packing)
+          const bool fits = (k0 | k1 | (k2 << 3)) < cell_lim;
+          const bool solid = keep[e] & fits & (max3_abs(gmid[0][e], gmid[1][e], gmid[2][e]) <= solid_lim);
+          cnt += solid ? 1u : 0u;
+          code[j0 + e] = solid ? ref_cell_code(k0, k1, k2) : FR_CODE_NONE;
+          const bool fragile = keep[e] & !solid;  // kept aside with its transformed coordinates: encoded with the frame's own offset below
+          const bool first_fr = fragile & (frag_mask == 0u);
+          sq0 = first_fr ? q[0][e] : sq0;
+          sq1 = first_fr ? q[1][e] : sq1;
+          sq2 = first_fr ? q[2][e] : sq2;
+          frag_mask |= fragile ? (1u << (j0 + e)) : 0u;
+        }
+      }
+      if (__any(cnt != 0u))
+      {
+        // the occupied bricks: one LDS atomic per run of the thread's consecutive codes in one brick
+        uint32_t cur = FR_CODE_NONE;
+#pragma unroll
+        for (int u = 0; u < IN_PPT; u++)
+        {
+          if (code[u] == FR_CODE_NONE)
+            continue;
+          const uint32_t b = code[u] >> 6;
+          if (b != cur)
+          {
+            if (cur != FR_CODE_NONE)
+            {
+              const uint32_t L = brick_lin(cur);
+              atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+            }
+            cur = b;
+          }
+        }
+        if (cur != FR_CODE_NONE)
+        {
+          const uint32_t L = brick_lin(cur);
+          atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
+        }
+        // the codes, appended to the wave's segment in point order (a wave-level scan: no barrier, no atomic)
+        const uint32_t incl = wave_incl_scan(cnt);
+        uint32_t* out = seg + wcnt + (incl - cnt);
+#pragma unroll
+        for (int j = 0; j < IN_PPT; j++)
+          if (code[j] != FR_CODE_NONE)
+            *out++ = code[j];
+        wcnt += __builtin_amdgcn_readlane(incl, 63);
+      }
+      if (__any(frag_mask != 0u))
+      {
+        // A fragile point leaves as its transformed coordinates (16 bytes with the slot of its code).  The first fragile point of
+        // a thread was kept in registers; a further one (0.3 % of the threads) is loaded again - its line is still in the cache -
+        // and transformed with the very expression of the loop above (packed or not, every operation rounds the same).
+        const uint32_t fcnt = __popc(frag_mask), fincl = wave_incl_scan(fcnt);
+        uint32_t fbase = 0;
+        if (lane == 63)
+          fbase = atomicAdd(&s_nfrag, fincl);
+        fbase = __builtin_amdgcn_readlane(fbase, 63);
+        if (frag_mask)
+        {
+          float4* fout = fragl + fbase + (fincl - fcnt);  // (at most one entry per point: the list holds pt_cap of them)
+          *fout++ = make_float4(sq0, sq1, sq2, 0.0f);
+          uint32_t rest = frag_mask & (frag_mask - 1u);
+          while (rest)
+          {
+            const uint32_t pi = i0 + static_cast<uint32_t>(__ffs(static_cast<int>(rest)) - 1);
+            rest &= rest - 1u;
+            const uint64_t st = PACKED ? 4u : a.stride;
+            const float p0 = ldf(a.x, st, pi), p1 = ldf(a.y, st, pi), p2 = ldf(a.z, st, pi);
+            float t3[3];
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+              t3[rr] = __fadd_rn(__fmul_rn(a.tf[4 * rr + 0], p0), __fadd_rn(__fmul_rn(a.tf[4 * rr + 1], p1), __fadd_rn(__fmul_rn(a.tf[4 * rr + 2], p2), a.tf[4 * rr + 3])));
+            *fout++ = make_float4(t3[0], t3[1], t3[2], 0.0f);
+          }
+        }
+      }
+#if FR_IN_PREFETCH
+#pragma unroll
+      for (int j = 0; j < IN_PPT; j++)
+        cx_[j] = nx[j], cy_[j] = ny[j], cz_[j] = nz[j];
+#endif
+    }
+    // bounding box of the frame (ordered ints: +-inf where a wave kept nothing - the identity of the min / max below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's codes and fragile points have left (other lanes / waves read them below)
+    wave_bbox(fmn, fmx);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        s_red[wave][c] = f2ord(fmn[c]);
+        s_red[wave][3 + c] = f2ord(fmx[c]);
+      }
+      s_wcnt[wave] = wcnt;
+    }
+  }
+  FR_STAMP(16);
+  __syncthreads();
+  FR_STAMP(17);
+  // ---- the frame's own lattice (voxel_grid_weighted.cpp:61-113) from the bounding box; whole cells between it and the reference
+  // lattice: both offsets are floats, their difference times inv lies within eps of an integer
+  if (tid == 0)
+  {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {static_cast<int>(0x80000000u), static_cast<int>(0x80000000u), static_cast<int>(0x80000000u)};
+    uint32_t tot = s_nfrag;
+    for (int w = 0; w < FR_THREADS / 64; w++)
+    {
+      tot += s_wcnt[w];
+      for (int c = 0; c < 3; c++)
+      {
+        mn[c] = min(mn[c], s_red[w][c]);
+        mx[c] = max(mx[c], s_red[w][3 + c]);
+      }
+    }
+    // (the lattice is worked out on a copy in registers and leaves for the header in one go: the header lives in global memory,
+    // and reading fields back right after writing them cost this single thread - and the 1023 waiting for it - ~20 us of round trips)
+    FrameHdr hl;
+    for (int c = 0; c < 3; c++)
+    {
+      hl.bb_min[c] = mn[c];
+      hl.bb_max[c] = mx[c];
+      hl.offset[c] = 0.0f;
+      hl.min_b[c] = hl.div_b[c] = 0;
+    }
+    hl.n_in = tot;
+    hl.status = VOFOD_OK;
+    hl.n_cells = hl.n_words = hl.need_words = 0;
+    grid_of_frame(g, hl);  // (an empty frame or a lattice beyond the index range: n_in = 0, status set)
+    for (int c = 0; c < 3; c++)
+    {
+      h.bb_min[c] = hl.bb_min[c];
+      h.bb_max[c] = hl.bb_max[c];
+      h.offset[c] = hl.offset[c];
+      h.min_b[c] = hl.min_b[c];
+      h.div_b[c] = hl.div_b[c];
+      s_lat[c] = hl.div_b[c];
+      s_latf[c] = hl.offset[c];
+    }
+    h.n_in = hl.n_in;
+    if (hl.status != VOFOD_OK)
+      h.status = hl.status;
+    h.n_cells = hl.n_cells;
+    h.n_words = hl.n_words;
+    h.need_words = hl.need_words;
+    s_lat[3] = static_cast<int>(hl.n_cells);
+    s_shift[3] = hl.n_in == 0 ? 1 : 0;
+    for (int c = 0; c < 3; c++)
+      s_shift[c] = hl.n_in ? static_cast<int>(rint((static_cast<double>(hl.offset[c]) - static_cast<double>(rl.off[c])) * static_cast<double>(g.inv[c]))) : 0;
+  }
+  FR_STAMP(18);
+  __syncthreads();
+  FR_STAMP(19);
+  if (s_shift[3])
+    return;  // k_init_hdr left V = C = 0
+  const uint32_t n_frag = s_nfrag;
+  uint32_t n_keys = n_frag;  // (codes of the frame: diagnostics only)
+  for (int w = 0; w < FR_THREADS / 64; w++)
+    n_keys += s_wcnt[w];
+  const int sh0 = s_shift[0], sh1 = s_shift[1], sh2 = s_shift[2];
+  // frame cell of reference cell 0 (frame cell = 4 * brick + bit + o)
+  const int o0 = -sh0, o1 = -sh1, o2 = -sh2;
+  const int dv0 = s_lat[0], dv1 = s_lat[1], dv2 = s_lat[2];  // the frame's own lattice
+  const int dx = dv0, dxy = dv0 * dv1;
+  const uint32_t n_cells = static_cast<uint32_t>(s_lat[3]);
+  const float hoff0 = s_latf[0], hoff1 = s_latf[1], hoff2 = s_latf[2];
   uint32_t* extras_g = sa.extras + static_cast<size_t>(FRAME) * pt_cap;
   constexpr int KPT = 16;  // consecutive codes per thread and round: points of one ring that share a voxel / brick are merged in registers
-  const bool vec_ok = ((reinterpret_cast<uintptr_t>(codes) | reinterpret_cast<uintptr_t>(codes_src)) & 15u) == 0u;
+  // a round of the wave's own segment: KPT consecutive codes per lane (the segment starts 16-byte aligned)
   auto load_codes = [&](uint32_t base, uint32_t c[KPT]) {
-    if (vec_ok && base + KPT <= n_keys)
+    if (base + KPT <= wcnt)
     {
 #pragma unroll
       for (int q = 0; q < KPT / 4; q++)
       {
-        const uint4 a = *reinterpret_cast<const uint4*>(codes + base + 4 * q);
-        c[4 * q] = a.x, c[4 * q + 1] = a.y, c[4 * q + 2] = a.z, c[4 * q + 3] = a.w;
+        const uint4 v = *reinterpret_cast<const uint4*>(seg + base + 4 * q);
+        c[4 * q] = v.x, c[4 * q + 1] = v.y, c[4 * q + 2] = v.z, c[4 * q + 3] = v.w;
       }
     }
     else
     {
 #pragma unroll
       for (int u = 0; u < KPT; u++)
-        c[u] = base + u < n_keys ? codes[base + u] : FR_CODE_NONE;
+        c[u] = base + u < wcnt ? seg[base + u] : FR_CODE_NONE;
     }
   };
-  uint32_t* codes_w = sa.keys + static_cast<size_t>(FRAME) * pt_cap;
-  // brick code of lattice cell (k0, k1, k2) of the frame's own lattice; a cell outside it (a rounding artefact) is aliased
-  // through the linear index as the reference does (voxel_grid_weighted.cpp:137) and dropped when it leaves the index range
-  const int dv0 = h.div_b[0], dv1 = h.div_b[1], dv2 = h.div_b[2];  // (the header lives in global memory: keep the lattice in registers)
-  const uint32_t n_cells = h.n_cells;
-  const float hoff0 = h.offset[0], hoff1 = h.offset[1], hoff2 = h.offset[2];
   if (tid == 0)
   {
     // Is the frame's lattice the map's lattice shifted by whole voxels?  (It is whenever the grid is aligned to the map, which
     // vofod_nodelet.cpp:664 always does.)  The float expression hasCloseTo's caller evaluates - floor((centre - map offset) / vs) -
     // is then cell + K for every cell: checked at both ends of every axis with the expression itself, the fractional part
-    // far from a cell boundary (the expression's rounding error grows by ~1e-7 per cell).
+    // far from a cell boundary (the expression's rounding error grows by ~1e-7 per cell).  Stored for REFERENCE cells: K - shift.
     const int dvs[3] = {dv0, dv1, dv2};
     const float hoffs[3] = {hoff0, hoff1, hoff2};
+    const int shs[3] = {sh0, sh1, sh2};
     int ok = 1;
-    for (int a = 0; a < 3; a++)
+    for (int ax = 0; ax < 3; ax++)
     {
       int K = 0;
       for (int e = 0; e < 2; e++)
       {
-        const int k = e == 0 ? 0 : dvs[a] - 1;
-        const float c = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k), 0.5f), g.leaf[a]), hoffs[a]);
-        const float t = __fmul_rn(__fsub_rn(c, mg.off[a]), mg.vs_inv);
+        const int k = e == 0 ? 0 : dvs[ax] - 1;
+        const float c = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k), 0.5f), g.leaf[ax]), hoffs[ax]);
+        const float t = __fmul_rn(__fsub_rn(c, mg.off[ax]), mg.vs_inv);
         const float fl = floorf(t), fr = t - fl;
         const int Ke = static_cast<int>(fl) - k;
         if (e == 0)
           K = Ke;
         ok &= (Ke == K) && fr > 0.25f && fr < 0.75f;
       }
-      s_mapk[a] = K;
+      s_mapk[ax] = K - shs[ax];
     }
     s_mapk[3] = ok;
   }
-  auto cell_code = [&](int k0, int k1, int k2) -> uint32_t {
+  // ---- the fragile points: exact expression with the frame's own offset (voxel_grid_weighted.cpp:131-136).  A cell outside the
+  // frame's lattice (a rounding artefact) is aliased through the linear index as the reference does (:137) and dropped when it
+  // leaves the index range.  Their codes stay in the side list (w of the entry): passes 3a / 3b read them there.
+  for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
+  {
+    const float4 q = fragl[i];
+    int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q.x, hoff0), g.inv[0])));
+    int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q.y, hoff1), g.inv[1])));
+    int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q.z, hoff2), g.inv[2])));
+    uint32_t cd = FR_CODE_NONE;
+    bool ok = true;
     // one unsigned compare per axis: negative values wrap above every lattice size
     if (static_cast<uint32_t>(k0) >= static_cast<uint32_t>(dv0) || static_cast<uint32_t>(k1) >= static_cast<uint32_t>(dv1) || static_cast<uint32_t>(k2) >= static_cast<uint32_t>(dv2))
     {
       const uint32_t key = static_cast<uint32_t>(k0 + k1 * dx + k2 * dxy);
-      if (key >= n_cells)
-        return FR_CODE_NONE;
-      k2 = static_cast<int>(key / static_cast<uint32_t>(dxy));
-      const uint32_t rem = key - static_cast<uint32_t>(k2) * dxy;
-      k1 = static_cast<int>(rem / static_cast<uint32_t>(dx));
-      k0 = static_cast<int>(rem - static_cast<uint32_t>(k1) * dx);
-    }
-    // brick coordinates packed like a node descriptor (fr_pack), then the bit inside the brick: no division is needed to get
-    // the coordinates back when the brick becomes a node (pass 3a)
-    return (fr_pack(static_cast<uint32_t>(k0 >> 2), static_cast<uint32_t>(k1 >> 2), static_cast<uint32_t>(k2 >> 2)) << 6) | static_cast<uint32_t>((k0 & 3) | ((k1 & 3) << 2) | ((k2 & 3) << 4));
-  };
-  // bit of a packed brick in the frame's brick bitmap
-  auto brick_lin = [&](uint32_t p) -> uint32_t { return (((p >> 18) & 63u) * static_cast<uint32_t>(nby) + ((p >> 9) & 511u)) * static_cast<uint32_t>(nbx) + (p & 511u); };
-  // whole cells between the reference lattice and this frame's: both offsets are floats, their difference times inv lies
-  // within eps of an integer
-  int shift[3] = {0, 0, 0};
-  if (rl.on)
-    for (int a = 0; a < 3; a++)
-      shift[a] = static_cast<int>(rint((static_cast<double>(h.offset[a]) - static_cast<double>(rl.off[a])) * static_cast<double>(g.inv[a])));
-  const int sh0 = shift[0], sh1 = shift[1], sh2 = shift[2];
-  auto ref_code = [&](uint32_t r) -> uint32_t {
-    return cell_code(static_cast<int>(r & 2047u) - sh0, static_cast<int>((r >> 11) & 2047u) - sh1, static_cast<int>(r >> 22) - sh2);
-  };
-  // the fragile points: exact expression with the frame's own offset (voxel_grid_weighted.cpp:131-136); their codes follow
-  // the reference cells in the list.
-  auto fragile_points = [&]() {
-    const uint32_t dst0 = n_ref;
-    const float* fq = reinterpret_cast<const float*>(sa.extras + static_cast<size_t>(SRC) * pt_cap);  // k_key1 left the transformed points
-    for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
-    {
-      const float q[3] = {fq[3 * i], fq[3 * i + 1], fq[3 * i + 2]};
-      const int k0 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[0], hoff0), g.inv[0])));
-      const int k1 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[1], hoff1), g.inv[1])));
-      const int k2 = static_cast<int>(floorf(__fmul_rn(__fsub_rn(q[2], hoff2), g.inv[2])));
-      uint32_t cd = cell_code(k0, k1, k2);
-      codes_w[dst0 + i] = cd;
-      if (cd != FR_CODE_NONE)
+      ok = key < n_cells;
+      if (ok)
       {
+        k2 = static_cast<int>(key / static_cast<uint32_t>(dxy));
+        const uint32_t rem = key - static_cast<uint32_t>(k2) * dxy;
+        k1 = static_cast<int>(rem / static_cast<uint32_t>(dx));
+        k0 = static_cast<int>(rem - static_cast<uint32_t>(k1) * dx);
+      }
+    }
+    if (ok)
+    {
+      const uint32_t r0 = static_cast<uint32_t>(k0 + sh0), r1 = static_cast<uint32_t>(k1 + sh1), r2 = static_cast<uint32_t>(k2 + sh2);
+      if (r0 < 4u * static_cast<uint32_t>(nbx) && r1 < 4u * static_cast<uint32_t>(nby) && r2 < 4u * static_cast<uint32_t>(nbz))  // (the frame's lattice lies inside the reference lattice)
+      {
+        cd = ref_cell_code(r0, r1, r2);
         const uint32_t L = brick_lin(cd >> 6);
         atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
       }
     }
-  };
-  if (rl.on)
-    fragile_points();
-  // ---- 1: the occupied bricks.  Consecutive codes of a thread mostly share their brick: one LDS atomic per run.
-  {
-    uint32_t c[KPT], cn[KPT];
-    const uint32_t n_pass1 = rl.on ? n_ref : n_keys;
-    auto load1 = [&](uint32_t base, uint32_t cc[KPT]) {
-      if (vec_ok && base + KPT <= n_pass1)
-      {
-#pragma unroll
-        for (int q = 0; q < KPT / 4; q++)
-        {
-          const uint4 a = *reinterpret_cast<const uint4*>(codes + base + 4 * q);
-          cc[4 * q] = a.x, cc[4 * q + 1] = a.y, cc[4 * q + 2] = a.z, cc[4 * q + 3] = a.w;
-        }
-      }
-      else
-      {
-#pragma unroll
-        for (int u = 0; u < KPT; u++)
-          cc[u] = base + u < n_pass1 ? codes[base + u] : FR_CODE_NONE;
-      }
-    };
-    uint32_t base = tid * KPT;
-    if (base < n_pass1)
-      load1(base, c);
-    for (; base < n_pass1; base += FR_THREADS * KPT)
-    {
-      if (base + FR_THREADS * KPT < n_pass1)
-        load1(base + FR_THREADS * KPT, cn);  // the next round's codes are on their way while this round works
-      if (rl.on)
-      {
-        // reference cells -> brick codes of the frame's lattice, written back for the later passes (converting again in
-        // pass 3a instead of writing here was measured: 9 us slower there, 1 us faster here)
-#pragma unroll
-        for (int u = 0; u < KPT; u++)
-          if (base + u < n_pass1)
-            c[u] = ref_code(c[u]);
-        if constexpr (FR_WRITE_BACK)
-        {
-          if (vec_ok && base + KPT <= n_pass1)
-          {
-#pragma unroll
-            for (int q = 0; q < KPT / 4; q++)
-              *reinterpret_cast<uint4*>(codes_w + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
-          }
-          else
-          {
-#pragma unroll
-            for (int u = 0; u < KPT; u++)
-              if (base + u < n_pass1)
-                codes_w[base + u] = c[u];
-          }
-        }
-      }
-      uint32_t cur = FR_CODE_NONE;
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-      {
-        if (c[u] == FR_CODE_NONE)
-          continue;
-        const uint32_t b = c[u] >> 6;
-        if (b != cur)
-        {
-          if (cur != FR_CODE_NONE)
-          {
-            const uint32_t L = brick_lin(cur);
-            atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
-          }
-          cur = b;
-        }
-      }
-      if (cur != FR_CODE_NONE)
-      {
-        const uint32_t L = brick_lin(cur);
-        atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
-      }
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-        c[u] = cn[u];
-    }
+    reinterpret_cast<uint32_t*>(fragl + i)[3] = cd;
   }
+  FR_STAMP(20);
   __syncthreads();
   FR_STAMP(1);
   // ---- 2: node indices = ranks of the set bits
@@ -979,37 +870,38 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   const uint32_t n = s_n;
   const uint32_t n_chunks = (n + 63u) >> 6;
   FR_STAMP(2);
-  // ---- 3a: occupancy words.  A thread ORs the run of its consecutive codes that share a brick with one LDS atomic per
-  // 32-bit half, and rewrites its codes as node * 64 + bit: the later passes need no bitmap lookup.
-  {
-    uint32_t c[KPT], cn[KPT];
-    uint32_t base = tid * KPT;
-    if (base < n_keys)
-      load_codes(base, c);
-    for (; base < n_keys; base += FR_THREADS * KPT)
-    {
-      if (base + FR_THREADS * KPT < n_keys)
-        load_codes(base + FR_THREADS * KPT, cn);
-      if constexpr (!FR_WRITE_BACK)
-      {
-        if (rl.on)  // pass 1 kept the reference cells in the list (the fragile points' codes behind them are brick codes already)
-        {
+  // ---- 3a: occupancy words.  A lane ORs the run of its consecutive codes that share a brick with one LDS atomic per
+  // 32-bit half, and rewrites its codes as node * 64 + bit: the counting pass needs no bitmap lookup.  Every wave walks its own
+  // segment of the code list (written by itself in the input pass: no other wave's stores are read here).  The first FR_REG_ROUNDS
+  // rounds of the segment (1 024 codes each) are fetched ONCE and stay in registers through both passes (rounds 2-4 read the
+  // list three times and wrote it twice: 5 x 47 MB per batch); a segment beyond them (a frame of more than ~49 k survivors) goes
+  // through the list in global memory as before.
+  constexpr int RR = FR_REG_ROUNDS;
+  uint32_t creg[RR > 0 ? RR : 1][KPT];
 #pragma unroll
-          for (int u = 0; u < KPT; u++)
-            if (base + u < n_ref)
-              c[u] = ref_code(c[u]);
-        }
-      }
+  for (int r = 0; r < RR; r++)
+  {
+    if (static_cast<uint32_t>(r) * 64u * KPT < wcnt)  // (wave-uniform)
+      load_codes(static_cast<uint32_t>(r) * 64u * KPT + lane * KPT, creg[r]);
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+        creg[r][u] = FR_CODE_NONE;
+    }
+  }
+  {
+    auto or_word = [&](uint32_t node, unsigned long long acc) {
+      uint32_t* w32 = reinterpret_cast<uint32_t*>(&s_word[node]);
+      const uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
+      if (lo)
+        atomicOr(&w32[0], lo);
+      if (hi)
+        atomicOr(&w32[1], hi);
+    };
+    auto words_round = [&](uint32_t (&c)[KPT]) {
       uint32_t cur = FR_CODE_NONE, cur_node = 0;
       unsigned long long acc = 0ull;
-      auto flush = [&]() {
-        uint32_t* w32 = reinterpret_cast<uint32_t*>(&s_word[cur_node]);
-        const uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
-        if (lo)
-          atomicOr(&w32[0], lo);
-        if (hi)
-          atomicOr(&w32[1], hi);
-      };
 #pragma unroll
       for (int u = 0; u < KPT; u++)
       {
@@ -1019,7 +911,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         if (b != cur)
         {
           if (cur != FR_CODE_NONE)
-            flush();
+            or_word(cur_node, acc);
           cur = b;
           cur_node = fr_node(s_bits64, s_pre, brick_lin(b));
           s_xyz[cur_node] = b;  // the code carries the brick's packed coordinates; every run of the brick writes the same value
@@ -1029,27 +921,157 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         c[u] = (cur_node << 6) | (c[u] & 63u);
       }
       if (cur != FR_CODE_NONE)
-        flush();
-      if (vec_ok && base + KPT <= n_keys)
+        or_word(cur_node, acc);
+    };
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+      if (static_cast<uint32_t>(r) * 64u * KPT < wcnt)
+        words_round(creg[r]);
+    for (uint32_t rb = static_cast<uint32_t>(RR) * 64u * KPT; rb < wcnt; rb += 64u * KPT)
+    {
+      const uint32_t base = rb + lane * KPT;
+      uint32_t c[KPT];
+      load_codes(base, c);
+      words_round(c);
+      if (base + KPT <= wcnt)
       {
 #pragma unroll
         for (int q = 0; q < KPT / 4; q++)
-          *reinterpret_cast<uint4*>(codes_w + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+          *reinterpret_cast<uint4*>(seg + base + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
       }
       else
       {
 #pragma unroll
         for (int u = 0; u < KPT; u++)
-          if (base + u < n_keys)
-            codes_w[base + u] = c[u];
+          if (base + u < wcnt)
+            seg[base + u] = c[u];
       }
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-        c[u] = cn[u];
+    }
+    // the fragile points' codes (the side list: a fraction of a percent of the frame), one per thread and round
+    for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
+    {
+      uint32_t* cw = reinterpret_cast<uint32_t*>(fragl + i) + 3;
+      const uint32_t cd = *cw;
+      if (cd == FR_CODE_NONE)
+        continue;
+      const uint32_t node = fr_node(s_bits64, s_pre, brick_lin(cd >> 6));
+      s_xyz[node] = cd >> 6;
+      or_word(node, 1ull << (cd & 63u));
+      *cw = (node << 6) | (cd & 63u);
     }
   }
   __syncthreads();
   FR_STAMP(3);
+  // ---- 3b: weights (voxel_grid_weighted.cpp:181).  The bitmap is parked in global memory; its LDS becomes one byte
+  // counter per voxel, indexed in brick order: first voxel of the node + set bits below.  Consecutive equal codes of a
+  // thread add once.  A counter that would pass 255 is undone and the points go to the frame's record list
+  // (node * 64 + bit | (points - 1) << 25), added to the stored weights after the emission.
+  uint32_t V = 0;
+  {
+    ulonglong2* bsave = reinterpret_cast<ulonglong2*>(fs.bbsave + static_cast<size_t>(FRAME) * FR_BB64);
+    for (int i = tid; i < FR_BB64 / 2; i += FR_THREADS)
+      bsave[i] = reinterpret_cast<const ulonglong2*>(s_bb)[i];
+    constexpr int NPT = LB_MAX / FR_THREADS;  // consecutive nodes per thread
+    uint32_t pc[NPT], sum = 0;
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+      const uint32_t i = tid * NPT + r;
+      pc[r] = i < n ? __popcll(s_word[i]) : 0u;
+      sum += pc[r];
+    }
+    const uint32_t incl = wave_incl_scan(sum);
+    if (lane == 63)
+      s_wsum[wave] = incl;
+    __syncthreads();  // (also: every thread has parked its part of the bitmap)
+    uint32_t run = incl - sum;
+    for (int w = 0; w < FR_THREADS / 64; w++)
+    {
+      const uint32_t x = s_wsum[w];
+      run += w < wave ? x : 0u;
+      V += x;
+    }
+    if (V > g.vox_cap)
+    {
+      if (tid == 0)
+      {
+        h.status = VOFOD_ERR_CAPACITY;  // as k_scan_b
+        h.V = 0;
+      }
+      return;
+    }
+    if (V > FR_CNT_CAP || V > 65535u)
+    {
+      if (tid == 0)
+      {
+        h.status = CCL_RETRY_STATUS;  // more voxels than byte counters: the batch takes the general kernels
+        h.V = 0;
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+      const uint32_t i = tid * NPT + r;
+      if (i < n)
+        s_vbase[i] = static_cast<uint16_t>(run);
+      run += pc[r];
+    }
+    for (uint32_t i = tid; i < (V + 15u) / 16u; i += FR_THREADS)
+      reinterpret_cast<uint4*>(s_bb)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  {
+    auto count = [&](uint32_t code, uint32_t add) {
+      const uint32_t node = code >> 6, bit = code & 63u;
+      const uint32_t idx = s_vbase[node] + __popcll(s_word[node] & ((1ull << bit) - 1ull));
+      const uint32_t sh = 8u * (idx & 3u);
+      const uint32_t old = atomicAdd(&s_cnt32[idx >> 2], add << sh);
+      if (((old >> sh) & 0xffu) + add > 255u)
+      {
+        atomicSub(&s_cnt32[idx >> 2], add << sh);
+        extras_g[atomicAdd(&s_ne, 1u)] = code | ((add - 1u) << 25);  // at most one record per point: the list holds pt_cap entries
+      }
+    };
+    auto count_round = [&](const uint32_t (&c)[KPT]) {
+      uint32_t last = FR_CODE_NONE, cntl = 0;
+#pragma unroll
+      for (int u = 0; u < KPT; u++)
+      {
+        if (c[u] == FR_CODE_NONE)
+          continue;
+        if (c[u] == last)
+        {
+          cntl++;
+          continue;
+        }
+        if (last != FR_CODE_NONE)
+          count(last, cntl);
+        last = c[u];
+        cntl = 1;
+      }
+      if (last != FR_CODE_NONE)
+        count(last, cntl);
+    };
+#pragma unroll
+    for (int r = 0; r < RR; r++)
+      if (static_cast<uint32_t>(r) * 64u * KPT < wcnt)
+        count_round(creg[r]);
+    for (uint32_t rb = static_cast<uint32_t>(RR) * 64u * KPT; rb < wcnt; rb += 64u * KPT)
+    {
+      uint32_t c[KPT];
+      load_codes(rb + lane * KPT, c);
+      count_round(c);
+    }
+    for (uint32_t i = tid; i < n_frag; i += FR_THREADS)
+    {
+      const uint32_t cd = reinterpret_cast<const uint32_t*>(fragl + i)[3];
+      if (cd != FR_CODE_NONE)
+        count(cd, 1u);
+    }
+  }
+  __syncthreads();
+  FR_STAMP(15);
   // ---- close first (round 4).  The reference only ever uses the FAR clusters (findCloseFarClusters, vofod_nodelet.cpp:727-748:
   // a cluster is close as soon as ONE member has a background voxel within hasCloseTo's stencil; close clusters feed nothing
   // but a per-voxel map update, :946) - and on a warmed map the ground sheet and the buildings, one giant close component, are
@@ -1069,7 +1091,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       constexpr int NPT = LB_MAX / FR_THREADS;
       const bool mapk_ok = s_mapk[3] != 0;
       const int K0 = s_mapk[0], K1 = s_mapk[1], K2 = s_mapk[2];
-      // one voxel by itself (a brick that leaves the map, or a lattice that is no translate of the map's): as phase E
+      // one voxel by itself (a brick that leaves the map, or a lattice that is no translate of the map's): as phase E; (k0, k1, k2): REFERENCE cell
       auto voxel_close = [&](int k0, int k1, int k2) -> bool {
         int mx_, my_, mz_;
         if (mapk_ok)
@@ -1080,9 +1102,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         }
         else
         {
-          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), hoff0);
-          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), hoff1);
-          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2), 0.5f), g.leaf[2]), hoff2);
+          const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0 + o0), 0.5f), g.leaf[0]), hoff0);
+          const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1 + o1), 0.5f), g.leaf[1]), hoff1);
+          const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k2 + o2), 0.5f), g.leaf[2]), hoff2);
           mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
           my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
           mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
@@ -1202,110 +1224,6 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       }
     }
   }
-  FR_STAMP(15);
-  // ---- 3b: weights (voxel_grid_weighted.cpp:181).  The bitmap is parked in global memory; its LDS becomes one byte
-  // counter per voxel, indexed in brick order: first voxel of the node + set bits below.  Consecutive equal codes of a
-  // thread add once.  A counter that would pass 255 is undone and the points go to the frame's record list
-  // (node * 64 + bit | (points - 1) << 25), added to the stored weights after the emission.
-  uint32_t V = 0;
-  {
-    ulonglong2* bsave = reinterpret_cast<ulonglong2*>(fs.bbsave + static_cast<size_t>(FRAME) * FR_BB64);
-    for (int i = tid; i < FR_BB64 / 2; i += FR_THREADS)
-      bsave[i] = reinterpret_cast<const ulonglong2*>(s_bb)[i];
-    constexpr int NPT = LB_MAX / FR_THREADS;  // consecutive nodes per thread
-    uint32_t pc[NPT], sum = 0;
-#pragma unroll
-    for (int r = 0; r < NPT; r++)
-    {
-      const uint32_t i = tid * NPT + r;
-      pc[r] = i < n ? __popcll(s_word[i]) : 0u;
-      sum += pc[r];
-    }
-    const uint32_t incl = wave_incl_scan(sum);
-    if (lane == 63)
-      s_wsum[wave] = incl;
-    __syncthreads();  // (also: every thread has parked its part of the bitmap)
-    uint32_t run = incl - sum;
-    for (int w = 0; w < FR_THREADS / 64; w++)
-    {
-      const uint32_t x = s_wsum[w];
-      run += w < wave ? x : 0u;
-      V += x;
-    }
-    if (V > g.vox_cap)
-    {
-      if (tid == 0)
-      {
-        h.status = VOFOD_ERR_CAPACITY;  // as k_scan_b
-        h.V = 0;
-      }
-      return;
-    }
-    if (V > FR_CNT_CAP || V > 65535u)
-    {
-      if (tid == 0)
-      {
-        h.status = CCL_RETRY_STATUS;  // more voxels than byte counters: the batch takes the general kernels
-        h.V = 0;
-      }
-      return;
-    }
-#pragma unroll
-    for (int r = 0; r < NPT; r++)
-    {
-      const uint32_t i = tid * NPT + r;
-      if (i < n)
-        s_vbase[i] = static_cast<uint16_t>(run);
-      run += pc[r];
-    }
-    for (uint32_t i = tid; i < (V + 15u) / 16u; i += FR_THREADS)
-      reinterpret_cast<uint4*>(s_bb)[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __syncthreads();
-  {
-    auto count = [&](uint32_t code, uint32_t add) {
-      const uint32_t node = code >> 6, bit = code & 63u;
-      const uint32_t idx = s_vbase[node] + __popcll(s_word[node] & ((1ull << bit) - 1ull));
-      const uint32_t sh = 8u * (idx & 3u);
-      const uint32_t old = atomicAdd(&s_cnt32[idx >> 2], add << sh);
-      if (((old >> sh) & 0xffu) + add > 255u)
-      {
-        atomicSub(&s_cnt32[idx >> 2], add << sh);
-        extras_g[atomicAdd(&s_ne, 1u)] = code | ((add - 1u) << 25);  // at most one record per point: the list holds pt_cap entries
-      }
-    };
-    uint32_t c[KPT], cn[KPT];
-    uint32_t base = tid * KPT;
-    if (base < n_keys)
-      load_codes(base, c);
-    for (; base < n_keys; base += FR_THREADS * KPT)
-    {
-      if (base + FR_THREADS * KPT < n_keys)
-        load_codes(base + FR_THREADS * KPT, cn);
-      uint32_t last = FR_CODE_NONE, cntl = 0;
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-      {
-        if (c[u] == FR_CODE_NONE)
-          continue;
-        if (c[u] == last)
-        {
-          cntl++;
-          continue;
-        }
-        if (last != FR_CODE_NONE)
-          count(last, cntl);
-        last = c[u];
-        cntl = 1;
-      }
-      if (last != FR_CODE_NONE)
-        count(last, cntl);
-#pragma unroll
-      for (int u = 0; u < KPT; u++)
-        c[u] = cn[u];
-    }
-  }
-  __syncthreads();
   FR_STAMP(14);
   // ---- 4: ranks in key order.  Pass a: one segmented scan per 64-node chunk; the per-node channel prefixes go to the
   // frame's scratch in global memory (L2), the sums of the chunk's last brick row to LDS (rows may span chunks).
@@ -1401,96 +1319,101 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
   }
   __syncthreads();
   FR_STAMP(4);
-  // Pass c: base rank of every lattice-row group in key order: q = (bz * 4 + zz) * nby + by (row occupancy from the parked bitmap)
+  // Pass c: base rank of every lattice row group in key order.  The groups of slab bz (4 lattice layers zz) come out zz-major,
+  // then by: Q(bz, zz, by) = S(bz) + sum_{zz' < zz} P(bz, zz') + sum_{by' < by} t(bz, by', zz), t = voxels of a brick row in layer zz.
+  // Round 5: ONE unsegmented block scan over the nodes (7 consecutive nodes per thread; a brick row's last node contributes the
+  // row's four layer totals): G_zz(row) = sum of t_zz over the rows before it in node order.  With Gs(bz) = G at the slab's first
+  // row:  Q = G_zz(row) + C(bz, zz),  C = sum_zz' Gs_zz'(bz) + sum_{zz' < zz} (Gs_zz'(next slab) - Gs_zz'(bz)) - Gs_zz(bz) - a
+  // table of 64 x 4 constants in LDS.  Only occupied rows are touched (rounds 2-4 walked all 4 * nby * nbz row groups, ten per thread,
+  // with two look-ups of the parked bitmap in global memory each: 8-16 us).
+  // (every prefix is below 65 536 - V is, checked in phase 3b -, so the four layers ride in the 16-bit fields of one 64-bit word)
   {
-    const unsigned long long* pk_bits = fs.bbsave + static_cast<size_t>(FRAME) * FR_BB64;
-    const uint16_t* pk_pre = reinterpret_cast<const uint16_t*>(pk_bits + FR_BW64 + 2);
-    const uint32_t nq = 4u * static_cast<uint32_t>(nby) * nbz;
-    const uint32_t qpt = (nq + FR_THREADS - 1) / FR_THREADS;  // <= 32
-    const uint32_t q0 = tid * qpt, q1 = min(q0 + qpt, nq);
-    // (plane, brick row) of a thread's first group by one division, then stepped; the sums of its first groups stay in
-    // registers between the two loops (each costs two bitmap look-ups in global memory)
-    auto row_sum = [&](uint32_t plane, uint32_t by, uint32_t& r_out, uint32_t& zz_out) -> uint32_t {
-      const uint32_t bz = plane >> 2, zz = plane & 3u;
-      const uint32_t r = bz * nby + by;
-      r_out = r;
-      zz_out = zz;
-      const uint32_t b0 = r * nbx, b1 = b0 + nbx;
-      const uint32_t n0 = fr_node(pk_bits, pk_pre, b0);
-      const uint32_t n1 = b1 < nb_total ? fr_node(pk_bits, pk_pre, b1) : n;
-      return n1 != n0 ? fr_hsum16(rowT[static_cast<size_t>(r) * 4 + zz]) : 0xffffffffu;  // 0xffffffff: the brick row is empty
-    };
-    constexpr int QC = 8;
-    uint32_t cache[QC];
-    const uint32_t plane0 = q0 / static_cast<uint32_t>(nby), by0 = q0 - plane0 * nby;
-    uint32_t sum = 0;
-    {
-      uint32_t plane = plane0, by = by0;
+    constexpr int NPT = LB_MAX / FR_THREADS;
+    const uint32_t i0 = static_cast<uint32_t>(tid) * NPT;
+    for (int s = tid; s < FR_MAX_NBZ + 1; s += FR_THREADS)
+      s_gs[s] = ~0ull;
+    uint32_t rows[NPT];  // the brick row a node is the last one of, or ~0
+    unsigned long long tz[NPT];
+    unsigned long long sum = 0ull;
+    uint32_t xyz_next = i0 < n ? s_xyz[i0] : 0u;
 #pragma unroll
-      for (int j = 0; j < QC; j++)
+    for (int r = 0; r < NPT; r++)
+    {
+      const uint32_t i = i0 + r;
+      rows[r] = 0xffffffffu;
+      if (i < n)
       {
-        cache[j] = 0xffffffffu;
-        if (q0 + j < q1)
-        {
-          uint32_t r, zz;
-          cache[j] = row_sum(plane, by, r, zz);
-          sum += cache[j] == 0xffffffffu ? 0u : cache[j];
-          if (++by == static_cast<uint32_t>(nby))
-          {
-            by = 0;
-            plane++;
-          }
-        }
-      }
-      for (uint32_t q = q0 + QC; q < q1; q++)
-      {
-        uint32_t r, zz;
-        const uint32_t sv = row_sum(plane, by, r, zz);
-        sum += sv == 0xffffffffu ? 0u : sv;
-        if (++by == static_cast<uint32_t>(nby))
-        {
-          by = 0;
-          plane++;
-        }
+        const uint32_t xyz = xyz_next;
+        xyz_next = i + 1 < n ? s_xyz[i + 1] : 0u;
+        const uint32_t row = fr_row(xyz, nby);
+        if (i + 1 == n || fr_row(xyz_next, nby) != row)
+          rows[r] = row;
       }
     }
-    const uint32_t incl = wave_incl_scan(sum);
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+      tz[r] = 0ull;
+      if (rows[r] != 0xffffffffu)
+      {
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(rowT + static_cast<size_t>(rows[r]) * 4);
+        const ulonglong2 t0 = src[0], t1 = src[1];
+        tz[r] = static_cast<unsigned long long>(fr_hsum16(t0.x)) | (static_cast<unsigned long long>(fr_hsum16(t0.y)) << 16) | (static_cast<unsigned long long>(fr_hsum16(t1.x)) << 32) |
+                (static_cast<unsigned long long>(fr_hsum16(t1.y)) << 48);
+        sum += tz[r];
+      }
+    }
+    unsigned long long incl = sum;
+    incl += dpp_mov0_64<0x111, 0xf>(incl);
+    incl += dpp_mov0_64<0x112, 0xf>(incl);
+    incl += dpp_mov0_64<0x114, 0xf>(incl);
+    incl += dpp_mov0_64<0x118, 0xf>(incl);
+    incl += dpp_mov0_64<0x142, 0xa>(incl);
+    incl += dpp_mov0_64<0x143, 0xc>(incl);
     if (lane == 63)
-      s_wsum[wave] = incl;
+      s_w4[wave] = incl;
     __syncthreads();
-    uint32_t run = incl - sum;
+    unsigned long long G = incl - sum, tot = 0ull;
     for (int w = 0; w < FR_THREADS / 64; w++)
     {
-      const uint32_t x = s_wsum[w];
-      run += w < wave ? x : 0u;
+      const unsigned long long x = s_w4[w];
+      G += w < wave ? x : 0ull;
+      tot += x;
     }
-    {
-      uint32_t plane = plane0, by = by0;
-      auto place = [&](uint32_t sv, uint32_t r, uint32_t zz) {
-        if (sv != 0xffffffffu)
-        {
-          rowQ[static_cast<size_t>(r) * 4 + zz] = run;
-          run += sv;
-        }
-        if (++by == static_cast<uint32_t>(nby))
-        {
-          by = 0;
-          plane++;
-        }
-      };
+    if (tid == 0)
+      s_gs[FR_MAX_NBZ] = tot;  // the sentinel behind the last slab
+    uint32_t bz_prev = (i0 > 0 && i0 < n) ? static_cast<uint32_t>(fr_bz(s_xyz[i0 - 1])) : 0xffffffffu;
 #pragma unroll
-      for (int j = 0; j < QC; j++)
-        if (q0 + j < q1)
-        {
-          const uint32_t bz = plane >> 2, zz = plane & 3u;
-          place(cache[j], bz * nby + by, zz);
-        }
-      for (uint32_t q = q0 + QC; q < q1; q++)
+    for (int r = 0; r < NPT; r++)
+    {
+      const uint32_t i = i0 + r;
+      if (i >= n)
+        break;
+      const uint32_t bz = static_cast<uint32_t>(fr_bz(s_xyz[i]));
+      if (bz != bz_prev)  // the slab's first node: every row of the slabs before has been added
+        s_gs[bz] = G;
+      bz_prev = bz;
+      if (rows[r] != 0xffffffffu)
       {
-        uint32_t r, zz;
-        const uint32_t sv = row_sum(plane, by, r, zz);
-        place(sv, r, zz);
+        // G of the row: the slab's constant is added where it is read
+        *reinterpret_cast<uint4*>(rowQ + static_cast<size_t>(rows[r]) * 4) =
+            make_uint4(static_cast<uint32_t>(G) & 0xffffu, static_cast<uint32_t>(G >> 16) & 0xffffu, static_cast<uint32_t>(G >> 32) & 0xffffu, static_cast<uint32_t>(G >> 48));
+        G += tz[r];
       }
+    }
+    __syncthreads();
+    if (tid < nbz && s_gs[tid] != ~0ull)
+    {
+      int nxt = tid + 1;
+      while (nxt < nbz && s_gs[nxt] == ~0ull)
+        nxt++;
+      if (nxt >= nbz)
+        nxt = FR_MAX_NBZ;
+      const unsigned long long ga = s_gs[tid], gb = s_gs[nxt];
+      const uint32_t g0 = static_cast<uint32_t>(ga) & 0xffffu, g1 = static_cast<uint32_t>(ga >> 16) & 0xffffu, g2 = static_cast<uint32_t>(ga >> 32) & 0xffffu, g3 = static_cast<uint32_t>(ga >> 48);
+      const uint32_t p0 = (static_cast<uint32_t>(gb) & 0xffffu) - g0, p1 = (static_cast<uint32_t>(gb >> 16) & 0xffffu) - g1, p2 = (static_cast<uint32_t>(gb >> 32) & 0xffffu) - g2;
+      const uint32_t S = g0 + g1 + g2 + g3;
+      *reinterpret_cast<uint4*>(&s_qc[tid][0]) = make_uint4(S - g0, S + p0 - g1, S + p0 + p1 - g2, S + p0 + p1 + p2 - g3);
     }
   }
   __syncthreads();
@@ -1512,7 +1435,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       for (int zz = 0; zz < 4; zz++)
         M[zz] += s_cin[i >> 6][zz];
     }
-    Q[0] = qq.x, Q[1] = qq.y, Q[2] = qq.z, Q[3] = qq.w;
+    const uint4 qc = *reinterpret_cast<const uint4*>(&s_qc[fr_bz(xyz)][0]);
+    Q[0] = qq.x + qc.x, Q[1] = qq.y + qc.y, Q[2] = qq.z + qc.z, Q[3] = qq.w + qc.w;
   };
   auto rank_of = [&](unsigned long long W, int p, const unsigned long long (&M)[4], const uint32_t (&Q)[4]) -> uint32_t {
     const int zz = p >> 4, yy = (p >> 2) & 3, xx = p & 3;
@@ -1546,7 +1470,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         for (int zz = 0; zz < 4; zz++)
           M[zz] += s_cin[i >> 6][zz];
       }
-      Q[0] = qq.x, Q[1] = qq.y, Q[2] = qq.z, Q[3] = qq.w;
+      const uint4 qc = *reinterpret_cast<const uint4*>(&s_qc[fr_bz(xyz)][0]);
+      Q[0] = qq.x + qc.x, Q[1] = qq.y + qc.y, Q[2] = qq.z + qc.z, Q[3] = qq.w + qc.w;
     }
     const int bx = fr_bx(xyz), by = fr_by(xyz), bz = fr_bz(xyz);
     unsigned long long w = W;
@@ -1561,7 +1486,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const uint32_t Qz = zz == 0 ? Q[0] : zz == 1 ? Q[1] : zz == 2 ? Q[2] : Q[3];
       const uint32_t nib = static_cast<uint32_t>(W >> (p & ~3)) & 0xfu;
       const uint32_t rank = Qz + (static_cast<uint32_t>(Mz >> (16 * yy)) & 0xffffu) + __popc(nib & ((1u << xx) - 1u));
-      const int k0 = 4 * bx + xx, k1 = 4 * by + yy, k2 = 4 * bz + zz;
+      const int k0 = 4 * bx + xx + o0, k1 = 4 * by + yy + o1, k2 = 4 * bz + zz + o2;  // the frame's own cell
       float4 pt;
       pt.x = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k0), 0.5f), g.leaf[0]), hoff0);
       pt.y = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(k1), 0.5f), g.leaf[1]), hoff1);
@@ -1606,7 +1531,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         az[u] = na[zz];
         a3[u] = na[3];
         tz[u] = ok ? rowT[static_cast<size_t>(r[u]) * 4 + zz] : 0ull;
-        qz[u] = ok ? rowQ[static_cast<size_t>(r[u]) * 4 + zz] : 0u;
+        qz[u] = ok ? rowQ[static_cast<size_t>(r[u]) * 4 + zz] + s_qc[fr_bz(s_xyz[node[u]])][zz] : 0u;
         wv[u] = s_word[node[u]];
       }
 #pragma unroll
@@ -1870,7 +1795,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
         const uint32_t t = s_pf[k];
         const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
         const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
-        if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, fr_bx(xb) - bx, fr_by(xb) - by, fr_bz(xb) - bz))
+        if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], 4 * bx + o0, 4 * by + o1, 4 * bz + o2, fr_bx(xb) - bx, fr_by(xb) - by, fr_bz(xb) - bz))
           continue;
         if (e & CF_OPEN_UNION)
           join(k, k2);
@@ -1923,8 +1848,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
       const unsigned long long ty = t | (t >> 16) | (t >> 32) | (t >> 48);
       const uint32_t oy = (static_cast<uint32_t>(ty) & 1u) | ((static_cast<uint32_t>(ty) >> 3) & 2u) | ((static_cast<uint32_t>(ty) >> 6) & 4u) | ((static_cast<uint32_t>(ty) >> 9) & 8u);
       const uint32_t oz = ((W & 0xffffull) ? 1u : 0u) | ((W & 0xffff0000ull) ? 2u : 0u) | ((W & 0xffff00000000ull) ? 4u : 0u) | ((W >> 48) ? 8u : 0u);
-      const int lo[3] = {4 * bx + __ffs(static_cast<int>(ox)) - 1, 4 * by + __ffs(static_cast<int>(oy)) - 1, 4 * bz + __ffs(static_cast<int>(oz)) - 1};
-      const int hi[3] = {4 * bx + 31 - __clz(static_cast<int>(ox)), 4 * by + 31 - __clz(static_cast<int>(oy)), 4 * bz + 31 - __clz(static_cast<int>(oz))};
+      const int lo[3] = {4 * bx + o0 + __ffs(static_cast<int>(ox)) - 1, 4 * by + o1 + __ffs(static_cast<int>(oy)) - 1, 4 * bz + o2 + __ffs(static_cast<int>(oz)) - 1};
+      const int hi[3] = {4 * bx + o0 + 31 - __clz(static_cast<int>(ox)), 4 * by + o1 + 31 - __clz(static_cast<int>(oy)), 4 * bz + o2 + 31 - __clz(static_cast<int>(oz))};
       atomicAdd(&a_size[root], static_cast<uint32_t>(__popcll(W)));
       atomicMin(&a_min[root], first);
       for (int a = 0; a < 3; a++)
@@ -2415,7 +2340,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     const uint32_t xa = s_xyz[t], xb = s_xyz[t2];
     const int bx = fr_bx(xa), by = fr_by(xa), bz = fr_bz(xa);
     const int ddx = fr_bx(xb) - bx, ddy = fr_by(xb) - by, ddz = fr_bz(xb) - bz;
-    if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], bx, by, bz, ddx, ddy, ddz))
+    if (!lb_pair_conn(s_tab, g, bp, h, s_word[t], s_word[t2], 4 * bx + o0, 4 * by + o1, 4 * bz + o2, ddx, ddy, ddz))
       continue;
     ra = lb_find(s_par, ra);
     rb = lb_find(s_par, rb);
@@ -2540,8 +2465,8 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
     unsigned long long ty = t | (t >> 16) | (t >> 32) | (t >> 48);
     const uint32_t oy = (static_cast<uint32_t>(ty) & 1u) | ((static_cast<uint32_t>(ty) >> 3) & 2u) | ((static_cast<uint32_t>(ty) >> 6) & 4u) | ((static_cast<uint32_t>(ty) >> 9) & 8u);
     const uint32_t oz = ((W & 0xffffull) ? 1u : 0u) | ((W & 0xffff0000ull) ? 2u : 0u) | ((W & 0xffff00000000ull) ? 4u : 0u) | ((W >> 48) ? 8u : 0u);
-    const int lo[3] = {4 * bx + __ffs(static_cast<int>(ox)) - 1, 4 * by + __ffs(static_cast<int>(oy)) - 1, 4 * bz + __ffs(static_cast<int>(oz)) - 1};
-    const int hi[3] = {4 * bx + 31 - __clz(static_cast<int>(ox)), 4 * by + 31 - __clz(static_cast<int>(oy)), 4 * bz + 31 - __clz(static_cast<int>(oz))};
+    const int lo[3] = {4 * bx + o0 + __ffs(static_cast<int>(ox)) - 1, 4 * by + o1 + __ffs(static_cast<int>(oy)) - 1, 4 * bz + o2 + __ffs(static_cast<int>(oz)) - 1};
+    const int hi[3] = {4 * bx + o0 + 31 - __clz(static_cast<int>(ox)), 4 * by + o1 + 31 - __clz(static_cast<int>(oy)), 4 * bz + o2 + 31 - __clz(static_cast<int>(oz))};
     uint32_t cnt = __popcll(W);
     bool hit = false;
     if (live && mapclose && !(c < LB_ST_ROWS ? st_close[c] : 0u))
@@ -2571,9 +2496,9 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
           }
           else
           {
-            const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + (p & 3)), 0.5f), g.leaf[0]), hoff0);
-            const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + ((p >> 2) & 3)), 0.5f), g.leaf[1]), hoff1);
-            const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + (p >> 4)), 0.5f), g.leaf[2]), hoff2);
+            const float cx = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bx + o0 + (p & 3)), 0.5f), g.leaf[0]), hoff0);
+            const float cy = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * by + o1 + ((p >> 2) & 3)), 0.5f), g.leaf[1]), hoff1);
+            const float cz = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(4 * bz + o2 + (p >> 4)), 0.5f), g.leaf[2]), hoff2);
             mx_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cx, mg.off[0]), mg.vs_inv)));
             my_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cy, mg.off[1]), mg.vs_inv)));
             mz_ = static_cast<int>(floorf(__fmul_rn(__fsub_rn(cz, mg.off[2]), mg.vs_inv)));
@@ -2770,7 +2695,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, co
 }
 
 // the instantiations under names without a comma (the launch macro records the kernel's name as written)
-constexpr auto k_frame_lds_full = &k_frame_lds<0>;  // voxelise + cluster everything (debug view, cold maps)
-constexpr auto k_frame_lds_far = &k_frame_lds<1>;   // voxelise + cluster the far voxels only (read-only batches)
+// (`_p`: every frame of the batch has packed float columns, 16-byte aligned, a multiple of 4 points - 16-byte loads in the input pass)
+constexpr auto k_frame_lds_full = &k_frame_lds<0, false>;   // voxelise + cluster everything (debug view, cold maps)
+constexpr auto k_frame_lds_full_p = &k_frame_lds<0, true>;
+constexpr auto k_frame_lds_far = &k_frame_lds<1, false>;    // voxelise + cluster the far voxels only (read-only batches)
+constexpr auto k_frame_lds_far_p = &k_frame_lds<1, true>;
 
 }  // namespace vk

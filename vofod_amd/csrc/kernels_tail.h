@@ -282,7 +282,9 @@ __global__ __launch_bounds__(TP_THREADS) void k_tail_prep(const GridParams g, co
 // the three tail kernels of a batch, one after the other on the tail stream, had become the pace of the pipeline).
 // Lane c = candidate cluster c: boxes + gates + explore job as k_tail_prep; then the wave runs the frame's flood fills
 // (explore_frame: the code of k_explore) and writes the detection records as k_tail_finish.
-__global__ __launch_bounds__(64) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
+// (five waves per SIMD = at most 96 registers: one of this kernel's waves then fits beside the four 104-register waves a frame
+// workgroup keeps on every SIMD - 4 x 104 + 96 = 512 - instead of waiting for a CU without one)
+__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(64) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
                                                 const CandMember* __restrict__ cand_all, VoxelArrays va_all, const MapGeom mg, const TailParams tp, const vc::ExploreParams ep, vc::ExploreJob* __restrict__ jobs,
                                                 int* __restrict__ members_out, float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all,
                                                 uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all,

@@ -252,6 +252,25 @@ struct Prof
     }                                                                        \
   } while (0)
 
+// (the same under another name in the profile: the instantiations of one kernel share their algorithmic name)
+#define KLAUNCH_AS(h, label, kern, grid, block, ...)                        \
+  do                                                                         \
+  {                                                                          \
+    if ((h)->prof.on)                                                        \
+    {                                                                        \
+      Prof::Rec r_{label, (h)->prof.get(), (h)->prof.get()};                 \
+      (void)hipEventRecord(r_.a, (h)->stream);                               \
+      hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+      (void)hipEventRecord(r_.b, (h)->stream);                               \
+      (h)->prof.recs.push_back(r_);                                          \
+    }                                                                        \
+    else                                                                     \
+    {                                                                        \
+      SlowCall sc_(label, __LINE__);                                         \
+      hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+    }                                                                        \
+  } while (0)
+
 // (the same with dynamic LDS)
 #define KLAUNCH_LDS(h, kern, grid, block, lds, ...)                                   \
   do                                                                         \
@@ -308,6 +327,7 @@ struct Workspace
   bool mapbits_patched = false;  // k_finalize_far kept the map's occupancy image and counters up to date with this scan's update
   bool prof_deferred = false;  // VOFOD_LDS_PROF=2: the frame kernel's stamps of this batch are printed when it is collected
   uint32_t prof_slot0 = 0;
+  bool in_packed = false;  // the batch's columns are packed, 16-byte aligned floats, a multiple of 4 points each: the frame kernel's input pass uses 16-byte loads
   bool far_ran = false;  // launch_cluster ran k_frame_lds_far: the cluster table and the member list are in the order k_tail_far reads
   int close_first = 0;  // k_frame_lds: 1 = cluster the far voxels only (read-only batches), 2 = the same with labels for the far-only debug view
   bool dtail = false;  // ... or its classification tail ran on the device (kernels_tail.h): only detection records come back
@@ -365,7 +385,7 @@ struct Workspace
       (void)hipFree(d_stage_aos);
     d_stage_aos = nullptr;
     stage_aos_bytes = 0;
-    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave};
+    void* ptrs[] = {d_bconn, ba.bricks, ba.bparent, ba.bmin, ba.bcmin, ba.blist, d_args, d_hdrs, d_bitmaps, d_wprefix, d_blocksums, va.pts, va.key, va.parent, va.csize, va.cbox, va.cclose, va.bb, d_labels, d_table, d_cand, d_ptrank, sa.extras, sa.counts, d_stage, d_packed, d_lite, d_tailc, d_dets, d_job_be, d_members_big, fs.rowT, fs.rowQ, fs.bmin, fs.nodeA, fs.bbsave, fs.frag};
     for (void* p : ptrs)
       if (p)
         (void)hipFree(p);
@@ -438,7 +458,9 @@ struct Workspace
     WS_ALLOC(d_labels, sizeof(uint32_t) * FV);
     WS_ALLOC(d_table, sizeof(ClusterRec) * FV);
     WS_ALLOC(d_cand, sizeof(CandMember) * FV);
-    WS_ALLOC(d_ptrank, sizeof(uint32_t) * static_cast<size_t>(F) * pt_cap);
+    // (the frame kernel's code list: every wave of a frame's workgroup appends to a segment of its own - whole rounds of the input pass)
+    fs.keys_cap = (pt_cap + IN_SEG_ALIGN - 1u) / IN_SEG_ALIGN * IN_SEG_ALIGN;
+    WS_ALLOC(d_ptrank, sizeof(uint32_t) * static_cast<size_t>(F) * fs.keys_cap);
     WS_ALLOC(sa.extras, sizeof(uint32_t) * static_cast<size_t>(F) * pt_cap);
     WS_ALLOC(sa.counts, sizeof(uint32_t) * 2 * F);
     sa.keys = d_ptrank;
@@ -454,6 +476,7 @@ struct Workspace
     WS_ALLOC(fs.bmin, sizeof(uint32_t) * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.nodeA, sizeof(unsigned long long) * 4 * LB_MAX * static_cast<size_t>(F));
     WS_ALLOC(fs.bbsave, sizeof(unsigned long long) * FR_BB64 * static_cast<size_t>(F));
+    WS_ALLOC(fs.frag, sizeof(float4) * static_cast<size_t>(F) * std::max<uint32_t>(pt_cap, 1));
 #undef WS_ALLOC
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_packed), sizeof(PackedFrame) * F)) != hipSuccess)
       return e;
@@ -1053,7 +1076,6 @@ inline uint32_t emit_split(uint32_t n_frames) { return n_frames <= 16 ? EMIT_SPL
 RefLattice fill_ref_lattice(const GridParams& g)
 {
   RefLattice rl{};
-  const bool on = !switch_off("VOFOD_ONEPASS");
   float cmax = 0.0f, dmax = 0.0f, inv_max = 0.0f;
   for (int a = 0; a < 3; a++)
   {
@@ -1071,7 +1093,13 @@ RefLattice fill_ref_lattice(const GridParams& g)
   const float e1 = 2.0f * (2.0f * cmax) * inv_max * u, e2 = 2.0f * cmax * u * inv_max + dmax * 2.0f * u;
   rl.eps = 4.0f * (e1 + e2) + 1e-4f;
   // (eps < 0.05: at most ~30 % of the points are fragile, and three words of the frame's side list hold each of them)
-  rl.on = on && rl.eps < 0.05f && rl.dims[0] > 0 && rl.dims[1] > 0 && rl.dims[2] > 0 && rl.dims[0] <= 2048 && rl.dims[1] <= 2048 && rl.dims[2] <= 1024;
+  // the frame kernel's bricks are bricks of this lattice: its brick bitmap has to fit LDS (LB_BITWORDS), its brick rows the
+  // per-frame row tables, the brick coordinates the fields of a code (9 + 9 + 6 bits)
+  for (int a = 0; a < 3; a++)
+    rl.nb[a] = (rl.dims[a] + 3) / 4;
+  const bool fits = rl.dims[0] > 0 && rl.dims[1] > 0 && rl.dims[2] > 0 && rl.nb[0] <= 512 && rl.nb[1] <= 512 && rl.nb[2] <= FR_MAX_NBZ &&
+                    static_cast<long long>(rl.nb[0]) * rl.nb[1] * rl.nb[2] <= static_cast<long long>(LB_BITWORDS) * 32 && static_cast<uint32_t>(rl.nb[1]) * rl.nb[2] <= FR_ROWS_MAX;
+  rl.on = rl.eps < 0.05f && fits;
   return rl;
 }
 
@@ -1091,60 +1119,43 @@ int launch_voxelize(vofod_handle* h, Workspace& ws, GridParams& g, uint32_t n, u
   HIPCHK(hipMemcpyAsync(ws.d_args, ws.h_args.data(), sizeof(FrameArgs) * n, hipMemcpyHostToDevice, h->stream));
   const uint32_t gx = std::max(1u, std::min((max_pts + 255u) / 256u, 1024u));
   const uint32_t gb = std::max(1u, std::min((max_pts + 2047u) / 2048u, 1024u));  // 8 points per thread: few header atomics
-  const bool frame_plan = ws.lean_emit && n >= 4 && !want_ptrank && !two_phase;
+  // Batches whose clustering will run inside LDS (plan_lds_ccl): the brick-first frame kernel (kernels_frame.h) reads the input
+  // itself (round 5; rounds 2-4: a streaming kernel k_key1 in front), builds the voxel records and clusters them on the same LDS
+  // image - launched by launch_cluster.  It needs the batch's reference lattice (bricks of the operation area's lattice in the
+  // LDS bitmap); where that does not fit, the general kernels below take the batch.
+  ws.ref_lattice = RefLattice{};
+  bool frame_plan = ws.lean_emit && n >= 4 && !want_ptrank && !two_phase;
+  if (frame_plan)
+  {
+    ws.ref_lattice = fill_ref_lattice(g);
+    frame_plan = ws.ref_lattice.on != 0;
+  }
   if (!frame_plan)
     ws.lean_emit = false;  // the general emission kernels initialise every per-voxel slot; the global clustering kernels follow
   const uint32_t lean_bit = ws.lean_emit ? 0x80000000u : 0u;
-  ws.ref_lattice = RefLattice{};
-  if (frame_plan)
-    ws.ref_lattice = fill_ref_lattice(g);
-  KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs, (frame_plan && ws.ref_lattice.on) ? ws.sa.counts : nullptr);
-  bool packed = frame_plan;
-  for (uint32_t f = 0; f < n && packed; f++)
-  {
-    const FrameArgs& a = ws.h_args[f];
-    packed = a.stride == 4 && (a.n & 3u) == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
-  }
-  if (frame_plan && ws.ref_lattice.on)
-  {
-    // one pass over the input: bounding box + reference cells (k_key1), then the frames' lattices
-    // (k_init_hdr has cleared the frames' list counters; one workgroup per KEY1_THREADS * KEY1_PPT points, no stride loop)
-    const uint32_t gk1 = std::max(1u, (max_pts + KEY1_THREADS * KEY1_PPT - 1) / (KEY1_THREADS * KEY1_PPT));
-    const dim3 gk(gk1, n);  // (blockIdx.y = frame: see k_key1)
-    if (packed)
-      KLAUNCH(h, k_key1<true>, gk, dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
-    else
-      KLAUNCH(h, k_key1<false>, gk, dim3(KEY1_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap, ws.ref_lattice);
-  }
-  else
-    KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
-  if (!(frame_plan && ws.ref_lattice.on))  // (k_frame_lds sets the lattice up itself behind k_key1)
-    KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
-  if (two_phase)
-    return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
-  // Batches whose clustering will run inside LDS (plan_lds_ccl): brick-first frame kernel (kernels_frame.h).  One pass over
-  // the input writes the survivors' brick codes; k_frame_lds (launched by launch_cluster) builds the voxel records and
-  // clusters them on the same LDS image.
+  KLAUNCH(h, k_init_hdr, dim3(n), dim3(64), ws.d_hdrs, static_cast<uint32_t*>(nullptr));
   ws.frame_fused = false;
   if (frame_plan)
   {
-    if (!ws.ref_lattice.on)
+    bool packed = true;
+    for (uint32_t f = 0; f < n && packed; f++)
     {
-      HIPCHK(hipMemsetAsync(ws.sa.counts, 0, sizeof(uint32_t) * 2 * n, h->stream));
-      const uint32_t gk = std::max(1u, (max_pts + KEY2_THREADS * KEY2_PPT - 1) / (KEY2_THREADS * KEY2_PPT));
-      if (packed)
-        KLAUNCH(h, k_key2<true>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
-      else
-        KLAUNCH(h, k_key2<false>, fgrid(g, gk), dim3(KEY2_THREADS), ws.d_args, g, ws.d_hdrs, ws.sa, ws.pt_cap);
+      const FrameArgs& a = ws.h_args[f];
+      packed = a.stride == 4 && (a.n & 3u) == 0 && a.n >= 4 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.z)) & 15u) == 0;
     }
+    ws.in_packed = packed;
     if (!h->ev_stagger)
       HIPCHK(hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(h->ev_stagger, h->stream));  // the next batch's chain may start its streaming kernels now
+    HIPCHK(hipEventRecord(h->ev_stagger, h->stream));  // the next batch's chain may start now
     h->ev_stagger_set = true;
     ws.frame_fused = true;
     HIPCHK(hipGetLastError());
     return VOFOD_OK;
   }
+  KLAUNCH(h, k_bbox, fgrid(g, gb), dim3(256), ws.d_args, g, ws.d_hdrs);
+  KLAUNCH(h, k_grid, dim3(n), dim3(64), g, ws.d_hdrs);
+  if (two_phase)
+    return VOFOD_OK;  // caller inspects the lattice size before the bitmap is touched
   // Lattices of at most SLAB_MAX slabs of 1 Mi cells: the bitmap is built slab by slab in LDS (kernels_slab.h).
   // VOFOD_SLABS=0 keeps the global-atomic kernels (also used for the counted grid, which needs every point's rank).
   const bool slabs_on = !switch_off("VOFOD_SLABS");
@@ -1383,7 +1394,7 @@ int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
       // a close-first frame: its own phases behind the emission
       auto us = [&](int a, int b) { return (t[32 * f + b] - t[32 * f + a]) * 0.01; };
       std::fprintf(stderr,
-                   "[k_frame_lds_far] frame %u: %.1f us | keys %llu V %llu bricks %llu pure-far bricks %llu far clusters %llu candidate members %llu | bits %.1f prefix %.1f words %.1f closebits %.1f count "
+                   "[k_frame_lds_far] frame %u: %.1f us | keys %llu V %llu bricks %llu pure-far bricks %llu far clusters %llu candidate members %llu | input+fragile %.1f prefix %.1f words %.1f count %.1f closebits "
                    "%.1f rank-a/b %.1f rank-c %.1f emit %.1f extras %.1f near+far %.1f open %.1f stats %.1f table %.1f members %.1f\n",
                    f, byd[q].first, t[32 * f + 27], t[32 * f + 29], t[32 * f + 26], t[32 * f + 24], t[32 * f + 25], t[32 * f + 30], us(0, 1), us(1, 2), us(2, 3), us(3, 15), us(15, 14), us(14, 4), us(4, 5),
                    us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 13));
@@ -1402,8 +1413,8 @@ int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
   // frames, us), one JSON object per launch appended to the file - profiles/r05_frame_phases.json is made of these
   if (const char* jf = std::getenv("VOFOD_LDS_PROF_JSON"); jf && !byd.empty() && t[32 * byd[0].second + 31] == ~0ull)
   {
-    static const int cuts[][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 15}, {15, 14}, {14, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}, {11, 13}, {0, 13}};
-    static const char* cnames[] = {"bits", "prefix", "words", "closebits", "count", "rank_ab", "rank_c", "emit", "extras_restore", "cf_edges", "cf_open", "cf_stats", "cf_table", "cf_members", "total"};
+    static const int cuts[][2] = {{0, 16}, {16, 17}, {17, 18}, {18, 19}, {19, 20}, {20, 1}, {1, 2}, {2, 3}, {3, 15}, {15, 14}, {14, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}, {11, 13}, {0, 13}};
+    static const char* cnames[] = {"input", "input_wait", "grid", "grid_wait", "fragile", "fragile_wait", "prefix", "words", "count", "closebits", "rank_ab", "rank_c", "emit", "extras_restore", "cf_edges", "cf_open", "cf_stats", "cf_table", "cf_members", "total"};
     if (FILE* fp = std::fopen(jf, "a"))
     {
       std::fprintf(fp, "{\"frames\": %zu, \"span_us\": %.1f, \"phases\": {", byd.size(), (t1 - t0) * 0.01);
@@ -1481,12 +1492,27 @@ int launch_cluster(vofod_handle* h, Workspace& ws, const GridParams& g, uint32_t
       {
         ws.frame_fused = false;
         ws.far_ran = up_tables && mapclose && ws.close_first;
+        // (four instantiations: close first or not, packed 16-byte column loads or strided ones; the profile names the algorithmic
+        // variant only: k_frame_lds_far / k_frame_lds_full)
+#define VOFOD_FRAME_LAUNCH(label, kern, UP, WT, CF)                                                                                                                                          \
+  KLAUNCH_AS(h, label, kern, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg, mapclose, \
+          h->d_mapbits, h->d_crows, h->closetab.n_rows, UP, ws.d_table, ws.d_cand, WT, d_prof, ws.ref_lattice, ws.d_args, CF)
+        const UpdateParams up_none{};
         if (ws.far_ran)  // read-only batches: cluster the far voxels only (the close-first instantiation)
-          KLAUNCH(h, k_frame_lds_far, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
-                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, *up_tables, ws.d_table, ws.d_cand, 1, d_prof, ws.ref_lattice, ws.d_args, ws.close_first);
+        {
+          if (ws.in_packed)
+            VOFOD_FRAME_LAUNCH("k_frame_lds_far", k_frame_lds_far_p, *up_tables, 1, ws.close_first);
+          else
+            VOFOD_FRAME_LAUNCH("k_frame_lds_far", k_frame_lds_far, *up_tables, 1, ws.close_first);
+        }
         else
-          KLAUNCH(h, k_frame_lds_full, dim3(n), dim3(FR_THREADS), g, bp, ct->d_lbtab, ws.d_hdrs, ws.sa, ws.pt_cap, ws.va, ws.d_labels, lb_limit, reinterpret_cast<uint32_t*>(ws.d_table), ws.fs, h->mg,
-                  mapclose, h->d_mapbits, h->d_crows, h->closetab.n_rows, up_tables ? *up_tables : UpdateParams{}, ws.d_table, ws.d_cand, (up_tables && mapclose) ? 1 : 0, d_prof, ws.ref_lattice, ws.d_args, 0);
+        {
+          if (ws.in_packed)
+            VOFOD_FRAME_LAUNCH("k_frame_lds_full", k_frame_lds_full_p, up_tables ? *up_tables : up_none, (up_tables && mapclose) ? 1 : 0, 0);
+          else
+            VOFOD_FRAME_LAUNCH("k_frame_lds_full", k_frame_lds_full, up_tables ? *up_tables : up_none, (up_tables && mapclose) ? 1 : 0, 0);
+        }
+#undef VOFOD_FRAME_LAUNCH
         ws.finalize_fused = up_tables && mapclose;
         if (d_prof && !ws.prof_deferred)
           if (const int pr = print_frame_prof(h, 0, n, true); pr != VOFOD_OK)
