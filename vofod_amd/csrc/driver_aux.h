@@ -718,10 +718,9 @@ void vofod_destroy(vofod_handle* h)
     (void)hipStreamDestroy(h->stream_tail);
   if (h->stream_key)
     (void)hipStreamDestroy(h->stream_key);
-  if (h->stream_frame)
-    (void)hipStreamDestroy(h->stream_frame);
-  if (h->stream_frame2)
-    (void)hipStreamDestroy(h->stream_frame2);
+  for (hipStream_t st : h->stream_frames)
+    if (st)
+      (void)hipStreamDestroy(st);
   for (int t = 1; t < vofod_handle::MAX_INFLIGHT; t++)
     if (h->chain_stream[t])
       (void)hipStreamDestroy(h->chain_stream[t]);
@@ -762,11 +761,19 @@ int vofod_create(const vofod_static_params* sp, const vofod_dyn_params* dp, vofo
     // next kernel boundary of the batches in flight instead of behind their queued kernels
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_tail, hipStreamNonBlocking, prio_hi));
+    int prio_tail = prio_hi;
+    if (const char* e = std::getenv("VOFOD_TAIL_PRIO"))  // (diagnostics) hi | mid | lo
+      prio_tail = e[0] == 'l' ? prio_lo : e[0] == 'm' ? (prio_lo + prio_hi) / 2 : prio_hi;
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_tail, hipStreamNonBlocking, prio_tail));
     // staged pipeline of submitted batches (process_frames): streaming kernels below the frame kernels
     CREATE_CHK(hipStreamCreateWithPriority(&h->stream_key, hipStreamNonBlocking, prio_lo));
-    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frame, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
-    CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frame2, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
+    // (VOFOD_FRAME_STREAMS: diagnostics - the number of frame streams, 1..8)
+    h->n_frame_streams = 2;  // (more streams cost more than they bring: 811 k / 763 k / 656 k frames/s with 2 / 4 / 8 of them, 32-frame batches 435 k / 268 k / 216 k)
+    if (const char* e = std::getenv("VOFOD_FRAME_STREAMS"))
+      h->n_frame_streams = std::min(std::max(std::atoi(e), 1), static_cast<int>(vofod_handle::MAX_FRAME_STREAMS));
+    for (int i = 0; i < h->n_frame_streams; i++)
+      CREATE_CHK(hipStreamCreateWithPriority(&h->stream_frames[i], hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
+    h->stream_frame = h->stream_frames[0];
   }
   h->chain_stream[0] = h->stream;
   // (tickets 1-3 have their streams from the start; tickets 4-7 - only small batches gain from more than four in flight - get

@@ -51,16 +51,31 @@ struct ExploreParams
   uint32_t stack_cap;  // entries per frame in the global work list / explored list
 };
 
+// (Round 5: the fences of the flood fill are workgroup-scope.  They only order the wave's own traffic - every frame slot has its
+// own work list, visited bits and overlay, and the words other lanes test are updated with atomics at L2.  Rounds 2-4 used
+// __threadfence(): an agent-scope fence writes back and invalidates the L2 of the wave's XCD on this multi-die part - a few hundred
+// of them per batch cost the frame kernels running beside the tail 14 % of their throughput: 967 k frames/s without the tail
+// kernel, 830 k with it.)
+// Memory ordering between the lanes of ONE wave (what __syncthreads() is in a 64-thread workgroup, where the compiler drops the
+// s_barrier): the tail kernels run several such waves - one frame each, diverging freely - in one workgroup, so a real barrier
+// would hang them.
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ uint32_t pack_rel(int dx, int dy, int dz) { return static_cast<uint32_t>((dx + 128) | ((dy + 128) << 8) | ((dz + 128) << 16)); }
 
-// The jobs jb..je of frame slot `slot`, in order, by the calling wave (a 64-thread workgroup); s_float: one byte per job,
-// s_walk: 6 * 32 bytes, both in LDS.  k_explore below and the fused tail of the close-first path (kernels_tail.h) run this.
+// The jobs jb..je of frame slot `slot`, in order, by the calling wave; s_float: one byte per job, s_walk: 6 * 32 bytes, both in LDS
+// and the wave's own.  k_explore below and the fused tail of the close-first path (kernels_tail.h) run this.
 __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const MapGeom& mg, const ExploreJob* __restrict__ jobs, const uint32_t jb, const uint32_t je, const int* __restrict__ members,
                                               float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all, uint32_t* __restrict__ explored_all,
                                               uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all, ExploreResult* __restrict__ results,
                                               uint32_t* __restrict__ visited_all, const uint32_t slot, uint8_t* s_float, uint8_t* s_walk)
 {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;  // (the calling wave: a 64-thread workgroup, or one wave of a wider one)
   if (jb == je)
     return;
   const uint64_t ovl_words = (mg.n + 63) >> 6;
@@ -142,7 +157,7 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
           }
           s_walk[e] = st;
         }
-        __syncthreads();
+        wave_sync();
         bool walk_ok = false;
         if (lane < 6)
         {
@@ -160,7 +175,7 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
           }
         }
         const bool any_walk = __ballot(walk_ok) != 0ull;
-        __syncthreads();
+        wave_sync();
         if (any_walk)
         {
           floating = false;
@@ -175,7 +190,7 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
         atomicOr(&visited[c >> 5], 1u << (c & 31));
         touched[0] = c;
       }
-      __syncthreads();
+      wave_sync();
       bool connected = false;
       while (n_stack > 0 && !connected)
       {
@@ -262,10 +277,10 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
         }
         n_stack = min(n_stack + total, ep.stack_cap);
         n_touched += total;
-        __syncthreads();  // stack / visited traffic of this round is complete before the next pop
+        wave_sync();  // stack / visited traffic of this round is complete before the next pop
       }
       // reset the visited bits this fill has set (only those: the bitset is 34 KB, a fill usually touches a few cells)
-      __syncthreads();
+      wave_sync();
       if (n_touched <= ep.stack_cap)
       {
         for (uint32_t e = lane; e < n_touched; e += 64)
@@ -274,8 +289,8 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
       else
         for (uint32_t w = lane; w < EX_WORDS; w += 64)
           __hip_atomic_store(&visited[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      __syncthreads();
+      __threadfence_block();
+      wave_sync();
       if (connected)
       {
         floating = false;
@@ -301,8 +316,8 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
         else
           map[li] = ep.frontier_value;
       }
-      __threadfence();
-      __syncthreads();
+      __threadfence_block();
+      wave_sync();
       m++;
     }
     if (lane == 0)
@@ -313,8 +328,8 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
       results[job.result_slot].conf_sum = 0.0;
     }
   }
-  __threadfence();
-  __syncthreads();
+  __threadfence_block();
+  wave_sync();
 
   // ---- phase 2: extractDetections' uncertainty sum for the floating clusters (vofod_nodelet.cpp:851-865)
   for (uint32_t j = jb; j < je; j++)
@@ -346,7 +361,7 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
   // ---- leave the overlay clean for the next call
   if (ep.no_update)
   {
-    __syncthreads();
+    wave_sync();
     const uint32_t n = __hip_atomic_load(&ovl_count_all[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n <= ep.stack_cap)
       for (uint32_t e = lane; e < n; e += 64)
@@ -354,7 +369,7 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
     else
       for (uint64_t w = lane; w < ovl_words; w += 64)
         overlay[w] = 0ull;
-    __syncthreads();
+    wave_sync();
     if (lane == 0)
       ovl_count_all[slot] = 0;
   }

@@ -48,6 +48,11 @@ constexpr uint32_t FR_ROWS_MAX = 8192;    // brick rows (nby * nbz) the per-fram
 constexpr uint32_t FR_CODE_NONE = 0xffffffffu;
 constexpr int FR_BB64 = FR_BW64 + 2 + FR_BW64 / 4;  // 64-bit words of the bitmap (+ 2 guard words) followed by its 16-bit prefix array
 constexpr uint32_t FR_CNT_CAP = FR_BB64 * 8;       // per-voxel byte counters that fit the same storage
+#ifndef FR_VGPR_CAP
+#define FR_VGPR_ATTR
+#else
+#define FR_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FR_VGPR_CAP)))
+#endif
 #ifndef FR_REG_ROUNDS_DEF
 #define FR_REG_ROUNDS_DEF 3
 #endif
@@ -336,7 +341,7 @@ __device__ __forceinline__ FrNodes fr_load_nodes(const unsigned long long* s_wor
 // Round 5: the kernel reads the input columns itself (phase "in"); PACKED: every frame of the batch has packed float
 // columns, 16-byte aligned, a multiple of 4 points (the host checks) - 16-byte loads; otherwise strided 4-byte loads.
 template <int CFM, bool PACKED>
-__global__ __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
+__global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const GridParams g, const BrickParams bp, const LbTables* __restrict__ tab, FrameHdr* hdrs, SlabArrays sa, uint32_t pt_cap,
                                                          VoxelArrays va_all, uint32_t* __restrict__ labels_all, uint32_t lb_limit, uint32_t* __restrict__ scratch_all, FrameScratch fs,
                                                          const MapGeom mg, const unsigned long long* __restrict__ mapclose, const unsigned long long* __restrict__ mapbits,
                                                          const CloseRow* __restrict__ crows, int n_crows, const UpdateParams up, ClusterRec* __restrict__ table_all,

@@ -22,6 +22,11 @@
 
 namespace vtd
 {
+
+#ifndef TAIL_WPB_DEF
+#define TAIL_WPB_DEF 4
+#endif
+constexpr int TAIL_WPB = TAIL_WPB_DEF;  // frames (waves) per workgroup of k_tail_far
 using namespace vk;
 
 constexpr int TP_THREADS = 256;
@@ -282,20 +287,28 @@ __global__ __launch_bounds__(TP_THREADS) void k_tail_prep(const GridParams g, co
 // the three tail kernels of a batch, one after the other on the tail stream, had become the pace of the pipeline).
 // Lane c = candidate cluster c: boxes + gates + explore job as k_tail_prep; then the wave runs the frame's flood fills
 // (explore_frame: the code of k_explore) and writes the detection records as k_tail_finish.
+// Round 5: TAIL_WPB waves (frames) per workgroup.  With one wave per workgroup the 256 tails of a batch were dealt out one by one,
+// each to the next CU a frame workgroup had just left - and a CU that holds even one such wave has no room for the next frame
+// workgroup (4 x 128 registers on every SIMD): the tails kept ~15 % of the CUs away from the frame kernels (967 k frames/s without
+// the tail kernel, 819 k with it).  Whole workgroups of tails fill a few CUs instead.
 // (five waves per SIMD = at most 96 registers: one of this kernel's waves then fits beside the four 104-register waves a frame
 // workgroup keeps on every SIMD - 4 x 104 + 96 = 512 - instead of waiting for a CU without one)
-__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(64) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
+__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
                                                 const CandMember* __restrict__ cand_all, VoxelArrays va_all, const MapGeom mg, const TailParams tp, const vc::ExploreParams ep, vc::ExploreJob* __restrict__ jobs,
                                                 int* __restrict__ members_out, float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all,
                                                 uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all,
                                                 vc::ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all, FrameDets* __restrict__ dets, FrameDets* __restrict__ hout,
                                                 TailCluster* __restrict__ tailc)
 {
-  __shared__ uint8_t s_float[TP_MAXC];
-  __shared__ uint8_t s_walk[6 * 32];
-  const uint32_t f = blockIdx.x;
+  __shared__ uint8_t s_float_all[TAIL_WPB][TP_MAXC];
+  __shared__ uint8_t s_walk_all[TAIL_WPB][6 * 32];
+  const uint32_t f = blockIdx.x * TAIL_WPB + (threadIdx.x >> 6);  // one wave per frame, TAIL_WPB frames per workgroup
+  if (f >= g.n_frames)
+    return;
+  uint8_t* s_float = s_float_all[threadIdx.x >> 6];
+  uint8_t* s_walk = s_walk_all[threadIdx.x >> 6];
   const FrameHdr h = hdrs[f];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   FrameDets& out = dets[f];
   uint32_t fallback = 0;
   const bool ok = h.status == VOFOD_OK;
@@ -431,10 +444,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(64) void
     return;
   }
   __threadfence_block();
-  __syncthreads();  // the jobs and their members' map voxels are written: the wave reads them back
+  vc::wave_sync();  // the jobs and their members' map voxels are written: the wave reads them back
   vc::explore_frame(ep, mg, jobs, jb, jb + n_jobs, members_out, map, overlay_all, stack_all, explored_all, touched_all, ovl_list_all, ovl_count_all, results, visited_all, f, s_float, s_walk);
   __threadfence_block();
-  __syncthreads();
+  vc::wave_sync();
   // the floating clusters (extractDetections :843-846) in cluster order, as k_tail_finish
   bool det = false, bad = false;
   double conf = 0.0;

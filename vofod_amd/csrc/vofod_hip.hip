@@ -544,8 +544,14 @@ struct vofod_handle
   hipStream_t stream = nullptr;
   hipStream_t stream_tail = nullptr;  // tail (k_explore) of collected async batches
   hipStream_t stream_key = nullptr;   // staged pipeline: streaming kernels of all submitted batches, lowest priority
-  hipStream_t stream_frame = nullptr; // staged pipeline: frame kernels of all submitted batches
-  hipStream_t stream_frame2 = nullptr; // frame kernels alternate between the two frame streams
+  // staged pipeline: the frame kernels of the submitted batches take the frame streams in turn.  A stream runs its kernels one
+  // after the other, and a frame kernel lasts from its first workgroup's start to its LAST workgroup's end - about two workgroup
+  // durations once the starts are staggered: with two streams a CU whose workgroup ended early had nothing to run until the other
+  // stream's previous kernel had drained completely (round 5: ~15 % of the CU time; the stamps of tools/phase_table.sh show it).
+  static constexpr int MAX_FRAME_STREAMS = 8;
+  hipStream_t stream_frames[MAX_FRAME_STREAMS] = {};
+  int n_frame_streams = 0;
+  hipStream_t stream_frame = nullptr;  // == stream_frames[0]
   int frame_toggle = 0;
   // Batches in flight.  Slots are allocated on first use.  Large batches gain nothing beyond four; small ones (whole chains side
   // by side, tails included) gain up to eight PROVIDED their streams do not share hardware queues - the runtime deals a process's
@@ -1417,7 +1423,10 @@ int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
     static const char* cnames[] = {"input", "input_wait", "grid", "grid_wait", "fragile", "fragile_wait", "prefix", "words", "count", "closebits", "rank_ab", "rank_c", "emit", "extras_restore", "cf_edges", "cf_open", "cf_stats", "cf_table", "cf_members", "total"};
     if (FILE* fp = std::fopen(jf, "a"))
     {
-      std::fprintf(fp, "{\"frames\": %zu, \"span_us\": %.1f, \"phases\": {", byd.size(), (t1 - t0) * 0.01);
+      double busy = 0;
+        for (auto& b : byd)
+          busy += b.first;
+        std::fprintf(fp, "{\"frames\": %zu, \"span_us\": %.1f, \"t0_abs_us\": %.1f, \"busy_us_sum\": %.1f, \"phases\": {", byd.size(), (t1 - t0) * 0.01, t0 * 0.01, busy);
       for (size_t c = 0; c < sizeof(cuts) / sizeof(cuts[0]); c++)
       {
         std::vector<double> v;
@@ -2023,7 +2032,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     // behind it.  Measured +2..4 % (541 / 533 / 533 k against 519 / 510 / 534 k frames/s, alternating runs on one box); the
     // pipeline's pace is then set by k_key1, which runs as a guest of the frame kernels all the time (one wave per SIMD beside a
     // frame workgroup: ~440 us per batch).
-    h->stream = (h->stream_frame2 && (h->frame_toggle ^= 1)) ? h->stream_frame2 : h->stream_frame;
+    h->frame_toggle = (h->frame_toggle + 1) % std::max(h->n_frame_streams, 1);
+    h->stream = h->stream_frames[h->frame_toggle];
     HIPCHK(hipStreamWaitEvent(h->stream, ws.ev_key, 0));
   }
 
@@ -2202,9 +2212,12 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     ep.no_update = no_update ? 1 : 0;
     ep.stack_cap = vc::EX_CELLS;
     // the records (135 KB) go straight into the pinned host slots from the last tail kernel: no copy command on any stream (see k_tail_finish)
-    if ((ws.far_ran && ws.close_first == 1) || far_single)
+    static const bool diag_no_tail = std::getenv("VOFOD_DIAG_NO_TAIL") != nullptr;  // (diagnostics: timing of the pipeline without the tail kernel - results are wrong)
+    if (diag_no_tail && n >= 128u)
+      ;
+    else if ((ws.far_ran && ws.close_first == 1) || far_single)
       // close-first frames: ordered lists from the frame kernel (or k_far_final), the whole tail in one kernel of one wave per frame
-      KLAUNCH(h, vtd::k_tail_far, dim3(n), dim3(64), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, ep, eb.d_jobs, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
+      KLAUNCH(h, vtd::k_tail_far, dim3((n + vtd::TAIL_WPB - 1) / vtd::TAIL_WPB), dim3(64 * vtd::TAIL_WPB), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, ep, eb.d_jobs, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
               eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited, ws.d_dets, ws.h_dets_dev, far_single ? ws.d_tailc : static_cast<vtd::TailCluster*>(nullptr));
     else
     {
