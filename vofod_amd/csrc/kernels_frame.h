@@ -468,6 +468,15 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
       asm volatile("" : "+v"(ex_hi[c]), "+v"(op_hi[c]));
     const float solid_lim = 0.5f - rl.eps;
     const float qnan = __int_as_float(0x7fc00000);
+    // (the brick lattice's dimensions in VECTOR registers for this loop: as scalars they were re-loaded from the kernel arguments
+    // inside every branch of the run merging below - the loop runs out of scalar registers -, each load a stall of the wave)
+    uint32_t v_nbx = static_cast<uint32_t>(nbx), v_nby = static_cast<uint32_t>(nby);
+    asm volatile("" : "+v"(v_nbx), "+v"(v_nby));
+    auto brick_lin_v = [&](uint32_t p) -> uint32_t { return (((p >> 18) & 63u) * v_nby + ((p >> 9) & 511u)) * v_nbx + (p & 511u); };
+    // a pixel without a return is exactly (0, 0, 0) (ouster_ros: range 0); where the exclude box holds the origin (it is the box around
+    // the sensor: vofod_nodelet.cpp:626-629) a wave whose 512 points of a round are all zero - a ring that looks at the sky - has
+    // nothing to do
+    const bool zero_dropped = g.ex_min[0] <= 0.0f && g.ex_min[1] <= 0.0f && g.ex_min[2] <= 0.0f && g.ex_max[0] >= 0.0f && g.ex_max[1] >= 0.0f && g.ex_max[2] >= 0.0f;
     const uint32_t cell_lim = 2048u;  // (k0 | k1 | k2 << 3) < 2048: the cell fits the code's fields (9 + 2, 9 + 2, 6 + 2 bits)
     auto load_round = [&](uint32_t r, float (&X)[IN_PPT], float (&Y)[IN_PPT], float (&Z)[IN_PPT]) {
       const uint32_t i0 = r * IN_ROUND + ((static_cast<uint32_t>(wave) + r) & (FR_THREADS / 64 - 1)) * (64u * IN_PPT) + static_cast<uint32_t>(lane) * IN_PPT;
@@ -524,6 +533,15 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
 #endif
       // (the waves take the round's 512-point pieces in turn: a wave sees every azimuth sector and ring parity - even load)
       const uint32_t i0 = r * IN_ROUND + ((static_cast<uint32_t>(wave) + r) & (FR_THREADS / 64 - 1)) * (64u * IN_PPT) + static_cast<uint32_t>(lane) * IN_PPT;
+      if (zero_dropped)
+      {
+        uint32_t nz_bits = 0;
+#pragma unroll
+        for (int j = 0; j < IN_PPT; j++)
+          nz_bits |= (__float_as_uint(px[j]) | __float_as_uint(py[j]) | __float_as_uint(pz[j])) & 0x7fffffffu;  // (-0.0 is zero too)
+        if (!__any(nz_bits != 0u))
+          continue;
+      }
       uint32_t code[IN_PPT];
       uint32_t cnt = 0, frag_mask = 0;
       float sq0 = 0.0f, sq1 = 0.0f, sq2 = 0.0f;  // transformed coordinates of the thread's FIRST fragile point of the round (8 % of the threads have one, 0.3 % a second)
@@ -604,7 +622,7 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
           {
             if (cur != FR_CODE_NONE)
             {
-              const uint32_t L = brick_lin(cur);
+              const uint32_t L = brick_lin_v(cur);
               atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
             }
             cur = b;
@@ -612,7 +630,7 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
         }
         if (cur != FR_CODE_NONE)
         {
-          const uint32_t L = brick_lin(cur);
+          const uint32_t L = brick_lin_v(cur);
           atomicOr(&s_bits[L >> 5], 1u << (L & 31u));
         }
         // the codes, appended to the wave's segment in point order (a wave-level scan: no barrier, no atomic)
