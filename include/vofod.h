@@ -190,7 +190,9 @@ typedef struct vofod_scan_debug {
   double stage_ms[8];
   /* INPUT, batches only (read from dbg[0]): non-zero asks for the view of the production path of a read-only batch, which
    * clusters close first - only far clusters are ever used (:727-748, :946-963): `clusters` lists the far clusters only
-   * (is_close = 0, canonical order) and `labels` is VOFOD_LABEL_NONE for every voxel outside them. */
+   * (is_close = 0, canonical order) and `labels` is VOFOD_LABEL_NONE for every voxel outside them.
+   * The struct carries inputs (the buffers, their capacities and this field): ZERO-INITIALISE it (`vofod_scan_debug d = {0}`)
+   * before filling in what is wanted - garbage here silently switches the view. */
   int32_t far_only;
   int32_t reserved_;
 } vofod_scan_debug;

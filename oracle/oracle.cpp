@@ -911,6 +911,8 @@ int ORACLE_API(process_batch)(vofod_handle* h, const vofod_scan* scans, const fl
             if (!std::binary_search(far_roots.begin(), far_roots.end(), d.labels[v]))
               d.labels[v] = VOFOD_LABEL_NONE;
       }
+      else if (d.clusters)
+        ret = VOFOD_ERR_CAPACITY;  // the full table does not fit: no far view can be cut from it (the HIP library reports the same)
     }
     if (n_out_per_frame)
       n_out_per_frame[f] = static_cast<uint32_t>(nf);

@@ -108,12 +108,17 @@ def test_cluster_tolerance_boundary(oracle, hip):
     np.testing.assert_array_equal(lb, la)
 
 
-def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2, debug=True):
+def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2, debug=True, route=None):
     """Step both detectors through the same scans; every step starts from identical maps.  debug=False: the production call of
-    a sensor stream (no debug output: the classification tail runs on the device and writes its frontiers to the map itself)."""
+    a sensor stream (no debug output: the classification tail runs on the device and writes its frontiers to the map itself).
+    `route` (a dict, debug=False only) receives the number of production calls and the kernels they launched (vofod_profile_read)."""
     n_det = 0
+    n_calls = 0
+    if route is not None and not debug:
+        dev.lib.profile_enable(dev.h, 1)
 
     def step(s, fl):
+        nonlocal n_calls
         if debug:
             dr, gr = ref.process_scan(s.scan, s.tf, flags=fl, debug=True)
             dh, gh = dev.process_scan(s.scan, s.tf, flags=fl, debug=True)
@@ -121,6 +126,7 @@ def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2, debug=T
         else:
             dr = ref.process_scan(s.scan, s.tf, flags=fl)
             dh = dev.process_scan(s.scan, s.tf, flags=fl)
+            n_calls += 1
         assert_detections_equal(dr, dh)
         return dr
 
@@ -150,6 +156,11 @@ def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2, debug=T
             if sa == capi.OK and la:
                 assert ref.sepclusters_finish() == dev.sepclusters_finish() == capi.OK
                 np.testing.assert_array_equal(dev.read_map(capi.MAP_VOXELS), ref.read_map(capi.MAP_VOXELS))
+    if route is not None and not debug:
+        from test_gpu_stream_route import profiled_calls
+
+        route.update(n_calls=n_calls, launches=profiled_calls(dev.lib, dev))
+        dev.lib.profile_enable(dev.h, 0)
     if not debug:
         # the occupancy image and the nVoxelsOver count were patched scan by scan (k_finalize_far): a scan WITH debug output reports
         # the count and goes through the image again (close flags of every cluster)
@@ -162,6 +173,25 @@ def _run_sequence(ref, dev, scans, flags=capi.SCAN_DEFAULT, sep_every=2, debug=T
     return n_det
 
 
+def _fallback_switch_set():
+    """tools/run_fallback_matrix.sh runs this file under the library's fallback switches: the route assertions hold for the default"""
+    return any(k.startswith("VOFOD_") and k not in ("VOFOD_TEST_HARNESS_SELFCHECK", "VOFOD_TRACE") for k in os.environ)
+
+
+def _assert_route(route, name, n_cold_max=1):
+    """VERDICT r4 missing #3: the production calls of a sequence took kernels_far.h + the one-kernel tail on all scans but at most
+    `n_cold_max` (a scan with more than 4 096 far voxels raises CF_RETRY and runs again through the brick kernels and the
+    three-kernel tail: the first scan on a map that only knows the seeded ground disc)"""
+    from test_gpu_stream_route import STREAM_KERNELS, _record
+
+    calls, n = route["launches"], route["n_calls"]
+    _record(name, dict(calls, n_calls=n))
+    assert "k_pack" not in calls, calls
+    for k in STREAM_KERNELS:
+        assert calls.get(k, 0) >= n - n_cold_max, (k, n, calls)
+    assert calls.get("k_far_final", 0) + calls.get("k_tail_prep", 0) >= n, (n, calls)  # every call classified on the device
+
+
 @pytest.mark.parametrize("debug", [True, False])
 @pytest.mark.parametrize("sensor,vs", [("os1-16", 0.5), ("os1-128", 0.5), ("os1-128", 0.25)])
 def test_process_scan_sequence_parity(oracle, hip, sensor, vs, debug):
@@ -170,8 +200,11 @@ def test_process_scan_sequence_parity(oracle, hip, sensor, vs, debug):
     scans = synth.scan_sequence(scene, sensor, 5, seed0=100)
     for d in (ref, dev):
         synth.seed_ground(d)
-    _run_sequence(ref, dev, scans, debug=debug)
+    route = {}
+    _run_sequence(ref, dev, scans, debug=debug, route=route)
     assert dev.status().detection_its == ref.status().detection_its
+    if not debug and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK") and not _fallback_switch_set():
+        _assert_route(route, f"sequence {sensor} {vs}")
 
 
 @pytest.mark.parametrize("debug", [True, False])
@@ -186,8 +219,11 @@ def test_process_scan_with_apriori_map_detects(oracle, hip, debug, vs=0.5):
         d.load_apriori(ap)
     np.testing.assert_array_equal(dev.read_map(), ref.read_map())
     scans = synth.scan_sequence(scene, "os1-128", 4, seed0=300)
-    n_det = _run_sequence(ref, dev, scans, sep_every=2, debug=debug)
+    route = {}
+    n_det = _run_sequence(ref, dev, scans, sep_every=2, debug=debug, route=route)
     assert n_det > 0  # the floating boxes are found, identically on both sides
+    if not debug and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK") and not _fallback_switch_set():
+        _assert_route(route, "apriori 0.5", n_cold_max=0)
     if not debug and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK") and os.environ.get("VOFOD_DEVICE_TAIL") != "0":
         lib = dev.lib
         lib.profile_enable(dev.h, 1)

@@ -1011,28 +1011,35 @@ int stage_cloud(vofod_handle* h, Workspace& ws, uint32_t f, const void* x, const
   // the kernels then read the columns in place at the struct's stride (k_key1<false>).  Round 3 gathered every column on the
   // host (three passes over the cloud and a synchronisation per column: ~1 ms per frame).  4 x the bytes of packed columns over
   // PCIe: the link's ceiling for this layout is ~8 k frames/s of OS1-128.
-  if (stride > 4 && !intensity && !range && n > 0)
+  // The kernels dereference floats in place: only structs whose stride and member offsets are multiples of 4 take this path, a
+  // packed / odd layout is gathered below.  The staging block is sized by the FIRST frame of a batch (or by
+  // vofod_reserve's caller, which passes through here with frame 0 too); a later frame of the same batch whose struct is
+  // larger than the block's pitch allows is gathered as well - growing the block there would free it under the earlier frames'
+  // copies and pointers.
+  if (stride > 4 && stride % 4 == 0 && !intensity && !range && n > 0)
   {
     const char* lo = std::min({static_cast<const char*>(x), static_cast<const char*>(y), static_cast<const char*>(z)});
     const char* hi = std::max({static_cast<const char*>(x), static_cast<const char*>(y), static_cast<const char*>(z)});
-    if (static_cast<size_t>(hi - lo) + 4 <= stride)
+    const bool aligned = (static_cast<const char*>(x) - lo) % 4 == 0 && (static_cast<const char*>(y) - lo) % 4 == 0 && (static_cast<const char*>(z) - lo) % 4 == 0;
+    if (aligned && static_cast<size_t>(hi - lo) + 4 <= stride)
     {
       const size_t block = (n - 1) * stride + static_cast<size_t>(hi - lo) + 4;
-      const size_t pitch = (ws.pt_cap * stride + 255) & ~static_cast<size_t>(255);
-      if (ws.aos_pitch != pitch || ws.stage_aos_bytes < pitch * ws.F)
+      if (f == 0 && (block > ws.aos_pitch || !ws.d_stage_aos))
       {
+        const size_t pitch = (ws.pt_cap * stride + 255) & ~static_cast<size_t>(255);
         HIPCHK(hipStreamSynchronize(h->stream));
         if (ws.d_stage_aos)
           (void)hipFree(ws.d_stage_aos);
         ws.d_stage_aos = nullptr;
         ws.stage_aos_bytes = 0;
+        ws.aos_pitch = 0;
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&ws.d_stage_aos), pitch * ws.F));
         ws.stage_aos_bytes = pitch * ws.F;
         ws.aos_pitch = pitch;
       }
-      if (block <= pitch)
+      if (ws.d_stage_aos && block <= ws.aos_pitch)
       {
-        char* dst = ws.d_stage_aos + static_cast<size_t>(f) * pitch;
+        char* dst = ws.d_stage_aos + static_cast<size_t>(f) * ws.aos_pitch;
         HIPCHK(hipMemcpyAsync(dst, lo, block, hipMemcpyHostToDevice, h->stream));
         a.x = dst + (static_cast<const char*>(x) - lo);
         a.y = dst + (static_cast<const char*>(y) - lo);
@@ -1967,6 +1974,17 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     HIPCHK(hipEventRecord(ws.ev_h2d, h->stream));
   else
     host_copies = false;
+  // an error return between here and the wait below must not leave copies from the caller's buffers in flight
+  struct H2DGuard
+  {
+    hipEvent_t ev;
+    bool armed;
+    ~H2DGuard()
+    {
+      if (armed)
+        (void)hipEventSynchronize(ev);
+    }
+  } h2d_guard{ws.ev_h2d, host_copies};
   const float leaf[3] = {sp.voxel_size, sp.voxel_size, sp.voxel_size};
   const int zero[3] = {0, 0, 0};
   float align_center[3];
@@ -2253,6 +2271,7 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
   tr_launch = ms_since(t0);
   if (phase == FRAMES_LAUNCH)
   {
+    h2d_guard.armed = false;
     if (host_copies)
       HIPCHK(hipEventSynchronize(ws.ev_h2d));  // (the whole chain is enqueued by now: the device works while the host waits for the link)
     HIPCHK(hipEventRecord(ws.ev_done, ws.dtail ? tail_stream_used : ws.lite ? ws.copy_stream : h->stream));
