@@ -368,21 +368,30 @@ def main():
             # 142 k frames/s, with sixteen 226-289 k; round 2's three in flight on the shared tail stream: 101-132 k.)
             depth32 = 8
 
+            host32 = {"submit": 0.0, "collect": 0.0, "n": 0}
+
             def run32(k):
                 infl = []
                 for _ in range(k):
+                    ta = time.perf_counter()
                     infl.append(det.batch_submit(sub, sub_tfs))
+                    tb = time.perf_counter()
                     if len(infl) == depth32:
                         det.batch_collect(infl.pop(0))
+                    host32["submit"] += tb - ta
+                    host32["collect"] += time.perf_counter() - tb  # (includes waiting for the oldest batch in flight)
+                    host32["n"] += 1
                 while infl:
                     det.batch_collect(infl.pop(0))
 
             run32(2 * depth32 + 4)  # (every ticket's workspace and buffers are allocated on first use: all of them before the clock starts)
             torch.cuda.synchronize()
+            host32.update(submit=0.0, collect=0.0, n=0)
             t1 = time.perf_counter()
             run32(100)
             torch.cuda.synchronize()
             dt32 = time.perf_counter() - t1
+            host_us = {"host_us_per_submit": round(1e6 * host32["submit"] / host32["n"], 1), "host_us_per_collect": round(1e6 * host32["collect"] / host32["n"], 1)}
             lib.profile_enable(det.h, 1)
             for _ in range(4):
                 det.process_batch(sub, sub_tfs)
@@ -391,7 +400,7 @@ def main():
             lib.profile_enable(det.h, 0)
             k32 = {knames[64 * i : 64 * i + 64].split(b"\0", 1)[0].decode(): round(1e3 * kms[i] / max(kcalls[i], 1), 1) for i in range(kn)}
             out["config3_share"] = {"frames_per_gpu_per_step": 32, "frames_per_s": 32 * 100 / dt32, "ms_per_step": 1e3 * dt32 / 100, "kernel_us": k32,
-                                    "batches_in_flight": depth32,
+                                    "batches_in_flight": depth32, **host_us,
                                     "note": "configs[3]'s per-GPU share (256 scans / 8 GPUs): 32-frame batches on this one GPU, eight in flight, each on a stream (and hardware queue) of its own with its own tail; a frame kernel of 32 workgroups leaves 7/8 of the CUs to the other batches in flight"}
         if world == 1 and args.loaded_tail_steps > 0:
             # the classification tail under load: twelve floating targets, nine of which appeared after the map was warmed

@@ -204,7 +204,10 @@ def test_process_scan_sequence_parity(oracle, hip, sensor, vs, debug):
     _run_sequence(ref, dev, scans, debug=debug, route=route)
     assert dev.status().detection_its == ref.status().detection_its
     if not debug and not os.environ.get("VOFOD_TEST_HARNESS_SELFCHECK") and not _fallback_switch_set():
-        _assert_route(route, f"sequence {sensor} {vs}")
+        # (a map that only knows the seeded ground disc is cold: a scan with more than 4 096 far voxels raises CF_RETRY, runs again
+        # through the brick kernels, and the close-first path stays off until the background has grown by a quarter - measured on
+        # the round-5 code: 9 / 6 of the 9 calls at OS1-16 / OS1-128 take kernels_far.h, the others the brick route)
+        _assert_route(route, f"sequence {sensor} {vs}", n_cold_max=route["n_calls"] // 2)
 
 
 @pytest.mark.parametrize("debug", [True, False])

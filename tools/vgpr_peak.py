@@ -34,5 +34,5 @@ for l in s[m.end():end].split('\n'):
         regs += [int(a), int(b)]
     if regs and max(regs) >= thr:
         hits[loc] += 1
-for (f, ln), c in sorted(hits.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+for (f, ln), c in sorted(((k, v) for k, v in hits.items() if k), key=lambda kv: (kv[0][0], kv[0][1])):
     print(f"{f}:{ln}  {c}")

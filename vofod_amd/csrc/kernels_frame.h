@@ -109,9 +109,6 @@ struct RefLattice
   int32_t on;
 };
 
-#ifndef FR_IN_PREFETCH
-#define FR_IN_PREFETCH 0
-#endif
 constexpr int IN_PPT = 8;                                  // consecutive points per thread and round of the input pass
 constexpr uint32_t IN_ROUND = FR_THREADS * IN_PPT;         // points per round and workgroup
 constexpr uint32_t IN_SEG_ALIGN = 16u * 64u * IN_PPT;      // the code list of a frame: 16 per-wave segments, each a whole number of rounds
@@ -401,11 +398,14 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the brick lattice: bricks of the reference lattice - the same for every frame of the batch
   const int nbx = rl.nb[0], nby = rl.nb[1], nbz = rl.nb[2];
-  const uint32_t nb_total = static_cast<uint32_t>(nbx) * nby * nbz;
 #define FR_STAMP(i)     \
   if (prof && tid == 0) \
   prof[static_cast<size_t>(FRAME) * 32 + (i)] = wall_clock64()
   FR_STAMP(0);
+  // (diagnostics: the CU this frame runs on - HW_ID: cu 11:8, sh 12, se 15:13; XCC_ID 3:0 - so that the stamps of the frames that
+  // followed each other on one CU can be laid end to end: tools/cu_gaps.py)
+  if (prof && tid == 0)
+    prof[static_cast<size_t>(FRAME) * 32 + 21] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) | static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 4));
   for (int s = tid; s < FR_BW64 + 2; s += FR_THREADS)
     s_bits64[s] = 0ull;
   for (int s = tid; s < static_cast<int>(sizeof(LbTables) / 4); s += FR_THREADS)
@@ -506,31 +506,16 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
         }
       }
     };
-#if FR_IN_PREFETCH
-    float cx_[IN_PPT], cy_[IN_PPT], cz_[IN_PPT];
-#endif
     for (uint32_t r = 0; r < in_rounds; r++)
     {
-      // (No software prefetch of the next round: the codes' stores sit between a prefetch and its use, conditional stores make the
-      // compiler's vmcnt bookkeeping give up - s_waitcnt vmcnt(0) - and every round then ended with a full drain of its own stores.
-      // Loads issued here, after the previous round's stores, are the youngest operations when they are waited for; the four waves
-      // of a SIMD cover each other's latency.)
+      // (No software prefetch of the next round.  Round 4: with the codes' stores between a prefetch and its use every round ended
+      // with a full drain of its own stores - vmcnt counts loads and stores alike.  Round 5: the clean form - wait at the top of the
+      // iteration, where this round's loads are the youngest operations in flight, then the previous round's stores, held in
+      // registers, then the next round's loads, then the work - compiles as intended (one s_waitcnt vmcnt(0) per round, at the
+      // top) and measures the same: 274.1 / 277.1 / 278.2 us against 276.1 / 279.3 / 279.1 us per 256 frames, interleaved on one box.
+      // The pass is not waiting for its loads: ~60 branches and ~540 vector instructions per wave and round are what it costs.)
       float px[IN_PPT], py[IN_PPT], pz[IN_PPT];
-#if FR_IN_PREFETCH
-      float nx[IN_PPT], ny[IN_PPT], nz[IN_PPT];
-      if (r == 0)
-        load_round(0, px, py, pz);
-      else
-      {
-#pragma unroll
-        for (int j = 0; j < IN_PPT; j++)
-          px[j] = cx_[j], py[j] = cy_[j], pz[j] = cz_[j];
-      }
-      if (r + 1 < in_rounds)
-        load_round(r + 1, nx, ny, nz);
-#else
       load_round(r, px, py, pz);
-#endif
       // (the waves take the round's 512-point pieces in turn: a wave sees every azimuth sector and ring parity - even load)
       const uint32_t i0 = r * IN_ROUND + ((static_cast<uint32_t>(wave) + r) & (FR_THREADS / 64 - 1)) * (64u * IN_PPT) + static_cast<uint32_t>(lane) * IN_PPT;
       if (zero_dropped)
@@ -671,11 +656,6 @@ __global__ FR_VGPR_ATTR __launch_bounds__(FR_THREADS) void k_frame_lds(const Gri
           }
         }
       }
-#if FR_IN_PREFETCH
-#pragma unroll
-      for (int j = 0; j < IN_PPT; j++)
-        cx_[j] = nx[j], cy_[j] = ny[j], cz_[j] = nz[j];
-#endif
     }
     // bounding box of the frame (ordered ints: +-inf where a wave kept nothing - the identity of the min / max below)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's codes and fragile points have left (other lanes / waves read them below)

@@ -30,121 +30,152 @@ struct RayParams
 
 __device__ __forceinline__ int c2i(float x, float off, float inv) { return static_cast<int>(floorf(__fmul_rn(__fsub_rn(x, off), inv))); }
 
+#ifndef RAY_ACC
+#define RAY_ACC 0  // diagnostics only (results wrong): 1 = the walk without the accumulation, 2 = plain stores instead of atomics
+#endif
+
+// One DDA walk per lane: the state of forEachRay (voxel_map.cpp:229-263) in a form without branches.
+//   tmax / tdelta as in the reference (the per-ray sequence tmax += tdelta is kept: same floats, same voxel sequence);
+//   rem[a]  = steps left on axis a before the walk would leave the map (cur[a] == last[a] of the reference <=> rem[a] == 0);
+//   lin     = linear index of the current voxel, moved by lstep[a] = step[a] * stride[a].
+struct RayWalk
+{
+  float tmax[3], tdelta[3], prev, length;
+  int rem[3], lstep[3];
+  uint32_t lin;
+  bool active;
+};
+
+// What bounds it (round 5, profiles/r05_raycast_variants.txt, one OS1-128 scan at 0.25 m): the float atomics.  The same kernel
+// without the accumulation: 78.5 us; with plain stores to the same addresses: 83.7 us; with the atomics: 218-222 us.  Tried and
+// not kept: two / four rays per lane for ILP (218.0 / 241.1 us against 219.8), and dealing the rays to the XCDs by azimuth sector
+// so that all rays through one wedge of the map are walked on one XCD and its L2 keeps the wedge's lines (221.7 us, 1 164 us at
+// OS2-128 x 2048 / 0.1 m against 1 168) - neither where the rays sit nor which L2 they go through changes what ~4 M single-float
+// read-modify-writes per scan cost.  The run merging below stays: without it there would be several times as many.
 __global__ __launch_bounds__(256) void k_raycast(const RayParams rp, const MapGeom mg, const char* __restrict__ intensity, const char* __restrict__ range, uint64_t stride,
                                                  const float* __restrict__ lut_dirs, const float* __restrict__ lut_offs, const uint8_t* __restrict__ mask,
                                                  float* __restrict__ ray, uint32_t* __restrict__ any_hit)
 {
-  const uint32_t idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = idx_raw < rp.n;
-  const uint32_t idx = alive ? idx_raw : 0u;
-  const float inten = *reinterpret_cast<const float*>(intensity + static_cast<uint64_t>(idx) * stride);
-  const uint32_t rng = *reinterpret_cast<const uint32_t*>(range + static_cast<uint64_t>(idx) * stride);
-  if (inten < rp.min_intensity || (!mask[idx] && rng == 0))  // vofod_nodelet.cpp:1449
-    alive = false;
-  float dir[3], start[3];
+  constexpr int RPL = 1;
+  const int lane = threadIdx.x & 63;
+  RayWalk w[RPL];
 #pragma unroll
-  for (int r = 0; r < 3; r++)
+  for (int k = 0; k < RPL; k++)
   {
-    const float* R = &rp.R[3 * r];
-    dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(R[0], lut_dirs[3 * idx]), __fmul_rn(R[1], lut_dirs[3 * idx + 1])), __fmul_rn(R[2], lut_dirs[3 * idx + 2]));
-    start[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(R[0], lut_offs[3 * idx]), __fmul_rn(R[1], lut_offs[3 * idx + 1])), __fmul_rn(R[2], lut_offs[3 * idx + 2])), rp.origin[r]);
-  }
-  const float ray_dist = __fmul_rn(0.001f, static_cast<float>(rng));                                  // :1455-1456
-  const float length = ray_dist == 0.0f ? rp.max_dist : fminf(__fsub_rn(ray_dist, rp.voxel_size), rp.max_dist);  // :1457
-  int cur[3] = {c2i(start[0], mg.off[0], mg.vs_inv), c2i(start[1], mg.off[1], mg.vs_inv), c2i(start[2], mg.off[2], mg.vs_inv)};
-  const int lim[3] = {mg.sx, mg.sy, mg.sz};
-  if (cur[0] < 0 || cur[0] >= lim[0] || cur[1] < 0 || cur[1] >= lim[1] || cur[2] < 0 || cur[2] >= lim[2])  // :1482
-    alive = false;
-  // forEachRay voxel_map.cpp:229-263
-  const float half = mg.vs / 2.0f;
-  float tdelta[3], tmax[3];
-  int step[3], last[3];
+    const uint32_t idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    bool alive = idx_raw < rp.n;
+    const uint32_t idx = alive ? idx_raw : 0u;
+    const float inten = *reinterpret_cast<const float*>(intensity + static_cast<uint64_t>(idx) * stride);
+    const uint32_t rng = *reinterpret_cast<const uint32_t*>(range + static_cast<uint64_t>(idx) * stride);
+    if (inten < rp.min_intensity || (!mask[idx] && rng == 0))  // vofod_nodelet.cpp:1449
+      alive = false;
+    float dir[3], start[3];
 #pragma unroll
-  for (int a = 0; a < 3; a++)
-  {
-    const float absdir = fabsf(dir[a]);
-    step[a] = (dir[a] > 0.0f) - (dir[a] < 0.0f);
-    tdelta[a] = __fmul_rn(__fdiv_rn(1.0f, absdir), mg.vs);
-    const float ctr = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cur[a]), 0.5f), mg.vs), mg.off[a]);
-    const float ctr_offset = __fsub_rn(ctr, start[a]);
-    tmax[a] = __fdiv_rn(__fadd_rn(half, __fmul_rn(static_cast<float>(step[a]), ctr_offset)), absdir);
-    last[a] = step[a] > 0 ? lim[a] - 1 : 0;
+    for (int r = 0; r < 3; r++)
+    {
+      const float* R = &rp.R[3 * r];
+      dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(R[0], lut_dirs[3 * idx]), __fmul_rn(R[1], lut_dirs[3 * idx + 1])), __fmul_rn(R[2], lut_dirs[3 * idx + 2]));
+      start[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(R[0], lut_offs[3 * idx]), __fmul_rn(R[1], lut_offs[3 * idx + 1])), __fmul_rn(R[2], lut_offs[3 * idx + 2])), rp.origin[r]);
+    }
+    const float ray_dist = __fmul_rn(0.001f, static_cast<float>(rng));                                             // :1455-1456
+    w[k].length = ray_dist == 0.0f ? rp.max_dist : fminf(__fsub_rn(ray_dist, rp.voxel_size), rp.max_dist);          // :1457
+    const int cur[3] = {c2i(start[0], mg.off[0], mg.vs_inv), c2i(start[1], mg.off[1], mg.vs_inv), c2i(start[2], mg.off[2], mg.vs_inv)};
+    const int lim[3] = {mg.sx, mg.sy, mg.sz};
+    if (cur[0] < 0 || cur[0] >= lim[0] || cur[1] < 0 || cur[1] >= lim[1] || cur[2] < 0 || cur[2] >= lim[2])  // :1482
+      alive = false;
+    // forEachRay voxel_map.cpp:229-263
+    const float half = mg.vs / 2.0f;
+    const int lstride[3] = {1, mg.sx, mg.sx * mg.sy};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+    {
+      const float absdir = fabsf(dir[a]);
+      const int step = (dir[a] > 0.0f) - (dir[a] < 0.0f);
+      w[k].tdelta[a] = __fmul_rn(__fdiv_rn(1.0f, absdir), mg.vs);
+      const float ctr = __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(cur[a]), 0.5f), mg.vs), mg.off[a]);
+      const float ctr_offset = __fsub_rn(ctr, start[a]);
+      w[k].tmax[a] = __fdiv_rn(__fadd_rn(half, __fmul_rn(static_cast<float>(step), ctr_offset)), absdir);
+      w[k].rem[a] = step > 0 ? lim[a] - 1 - cur[a] : cur[a];  // (last[a] = step > 0 ? lim - 1 : 0, :246)
+      w[k].lstep[a] = step * lstride[a];
+    }
+    w[k].lin = alive ? static_cast<uint32_t>((static_cast<uint64_t>(cur[2]) * mg.sy + cur[1]) * mg.sx + cur[0]) : 0u;
+    w[k].prev = 0.0f;
+    w[k].active = alive && 0.0f < w[k].length;
   }
   // Neighbouring lanes are neighbouring azimuth columns of one ring: their walks visit almost the same voxels in
   // almost the same order, so per DDA step the wave merges runs of lanes that sit in the same voxel (segmented
-  // shuffle sum) and issues one float atomic per run instead of one per lane.  The loop is kept wave-uniform.
-  float prev = 0.0f;
+  // sum) and issues one float atomic per run instead of one per lane.  The loop is kept wave-uniform.
   bool any = false;
-  bool active = alive && prev < length;
-  const int lane = threadIdx.x & 63;
-  while (__ballot(active))
+  while (true)
   {
-    uint32_t key = 0xffffffffu;
-    float dd = 0.0f;
-    if (active)
+    bool go = false;
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+      go |= w[k].active;
+    if (!__ballot(go))
+      break;
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
     {
-      int i = 0;
-      if (tmax[1] < tmax[i])
-        i = 1;
-      if (tmax[2] < tmax[i])
-        i = 2;
-      const float dist = i == 0 ? tmax[0] : (i == 1 ? tmax[1] : tmax[2]);
-      dd = __fsub_rn(fminf(dist, length), prev);
-      if (dd != 0.0f)
-        key = static_cast<uint32_t>((static_cast<uint64_t>(cur[2]) * mg.sy + cur[1]) * mg.sx + cur[0]);
-      prev = dist;
-      const int ci = i == 0 ? cur[0] : (i == 1 ? cur[1] : cur[2]);
-      const int li = i == 0 ? last[0] : (i == 1 ? last[1] : last[2]);
-      if (ci == li)
-        active = false;
-      else
+      RayWalk& r = w[k];
+      // the axis of the smallest tmax, first minimum on ties (Eigen's minCoeff, voxel_map.cpp:252)
+      const bool s1 = r.tmax[1] < r.tmax[0];
+      const float m01 = s1 ? r.tmax[1] : r.tmax[0];
+      const bool s2 = r.tmax[2] < m01;
+      const float dist = s2 ? r.tmax[2] : m01;
+      float dd = __fsub_rn(fminf(dist, r.length), r.prev);
+      dd = r.active ? dd : 0.0f;
+      const uint32_t key = dd != 0.0f ? r.lin : 0xffffffffu;
+      const int remi = s2 ? r.rem[2] : (s1 ? r.rem[1] : r.rem[0]);
+      const bool adv = r.active & (remi != 0);
+      const bool a2 = adv & s2, a1 = adv & s1 & !s2, a0 = adv & !s1 & !s2;
+      r.tmax[0] = a0 ? __fadd_rn(r.tmax[0], r.tdelta[0]) : r.tmax[0];
+      r.tmax[1] = a1 ? __fadd_rn(r.tmax[1], r.tdelta[1]) : r.tmax[1];
+      r.tmax[2] = a2 ? __fadd_rn(r.tmax[2], r.tdelta[2]) : r.tmax[2];
+      r.rem[0] -= a0 ? 1 : 0;
+      r.rem[1] -= a1 ? 1 : 0;
+      r.rem[2] -= a2 ? 1 : 0;
+      r.lin += static_cast<uint32_t>(a0 ? r.lstep[0] : (a1 ? r.lstep[1] : (a2 ? r.lstep[2] : 0)));
+      r.prev = r.active ? dist : r.prev;
+      r.active = adv & (dist < r.length);
+      // Runs of lanes in one voxel: segmented inclusive sum with DPP moves (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: vector ALU
+      // only, no LDS crossbar).  The last lane of a run holds its total and issues the atomic.
+      const uint32_t kprev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(~key), static_cast<int>(key), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      const bool head = lane == 0 || kprev != key;
+      uint32_t f = head ? 1u : 0u;
+      float run = dd;
+      auto segstep = [&](auto ctrl_tag, auto mask_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+        const float t = __uint_as_float(dpp_mov0<CTRL, MASK>(__float_as_uint(run)));
+        const uint32_t ft = dpp_mov0<CTRL, MASK>(f);
+        run = f ? run : __fadd_rn(run, t);
+        f |= ft;
+      };
+      segstep(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+      segstep(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+      segstep(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+      segstep(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+      segstep(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+      segstep(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+      const unsigned long long H = __ballot(head);
+      const bool tail = lane == 63 || ((H >> (lane + 1)) & 1ull);
+#if RAY_ACC == 1
+      if (tail && key != 0xffffffffu && run == 12345.678f)
+#else
+      if (tail && key != 0xffffffffu)
+#endif
       {
-        if (i == 0)
-        {
-          cur[0] += step[0];
-          tmax[0] = __fadd_rn(tmax[0], tdelta[0]);
-        }
-        else if (i == 1)
-        {
-          cur[1] += step[1];
-          tmax[1] = __fadd_rn(tmax[1], tdelta[1]);
-        }
-        else
-        {
-          cur[2] += step[2];
-          tmax[2] = __fadd_rn(tmax[2], tdelta[2]);
-        }
-        active = prev < length;
+#if RAY_ACC == 2
+        ray[key] = run;
+#elif RAY_ACC == 3
+        atomicAdd(reinterpret_cast<unsigned int*>(ray) + key, __float_as_uint(run));  // (timing of an integer atomic on the same addresses)
+#elif RAY_ACC == 4
+        atomicAdd(reinterpret_cast<unsigned long long*>(ray) + (key >> 1), static_cast<unsigned long long>(__float_as_uint(run)));
+#else
+        unsafeAtomicAdd(&ray[key], run);
+#endif
+        any = true;
       }
-    }
-    // Runs of lanes in one voxel: segmented inclusive sum with DPP moves (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: vector ALU
-    // only, no LDS crossbar; round 3: 229 -> 220 us).  The last lane of a run holds its total and issues the atomic.
-    // (What bounds the kernel is neither the shuffles nor the atomics - leaving the first 5 m of every ray out of the
-    // accumulation changed 229 to 209 us - but the walk itself: ~130 instructions per DDA step, up to ~140 steps, and only
-    // 2 048 waves for 1 024 SIMDs: two waves per SIMD cannot hide each other's dependent chains.)
-    const uint32_t kprev = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(~key), static_cast<int>(key), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-    const bool head = lane == 0 || kprev != key;
-    uint32_t f = head ? 1u : 0u;
-    float run = dd;
-    auto segstep = [&](auto ctrl_tag, auto mask_tag) {
-      constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
-      const float t = __uint_as_float(dpp_mov0<CTRL, MASK>(__float_as_uint(run)));
-      const uint32_t ft = dpp_mov0<CTRL, MASK>(f);
-      run = f ? run : __fadd_rn(run, t);
-      f |= ft;
-    };
-    segstep(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
-    segstep(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
-    segstep(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
-    segstep(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
-    segstep(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
-    segstep(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
-    const unsigned long long H = __ballot(head);
-    const bool tail = lane == 63 || ((H >> (lane + 1)) & 1ull);
-    if (tail && key != 0xffffffffu)
-    {
-      unsafeAtomicAdd(&ray[key], run);
-      any = true;
     }
   }
   if (any)

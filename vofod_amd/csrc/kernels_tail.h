@@ -24,9 +24,14 @@ namespace vtd
 {
 
 #ifndef TAIL_WPB_DEF
-#define TAIL_WPB_DEF 4
+#define TAIL_WPB_DEF 8
 #endif
 constexpr int TAIL_WPB = TAIL_WPB_DEF;  // frames (waves) per workgroup of k_tail_far
+#if TAIL_WPB_DEF >= 16
+#define TAIL_OCC_ATTR
+#else
+#define TAIL_OCC_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+#endif
 using namespace vk;
 
 constexpr int TP_THREADS = 256;
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tail_prep(const GridParams g, co
 // the tail kernel, 819 k with it).  Whole workgroups of tails fill a few CUs instead.
 // (five waves per SIMD = at most 96 registers: one of this kernel's waves then fits beside the four 104-register waves a frame
 // workgroup keeps on every SIMD - 4 x 104 + 96 = 512 - instead of waiting for a CU without one)
-__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
+__global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const GridParams g, const FrameHdr* __restrict__ hdrs, const FrameArgs* __restrict__ args, const ClusterRec* __restrict__ table_all,
                                                 const CandMember* __restrict__ cand_all, VoxelArrays va_all, const MapGeom mg, const TailParams tp, const vc::ExploreParams ep, vc::ExploreJob* __restrict__ jobs,
                                                 int* __restrict__ members_out, float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all,
                                                 uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all,

@@ -1382,6 +1382,39 @@ int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
   if (sync)
     HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(t.data(), d_prof + 32 * static_cast<size_t>(s0), sizeof(unsigned long long) * 32 * cnt, hipMemcpyDeviceToHost));
+  if (const char* rawf = std::getenv("VOFOD_LDS_PROF_RAW"))
+  {
+    // raw mode: nothing is formatted while the pipeline runs (the JSON table below costs the host ~100 us per launch: 840 k instead
+    // of 950 k frames/s) - every frame's start, end and CU are kept and written to the named file when the process ends
+    // (tools/cu_gaps.py lays the frames of every CU end to end)
+    struct RawLog
+    {
+      std::vector<unsigned long long> v;  // launch, start, end, hw id per frame
+      std::string path;
+      uint64_t launch = 0;
+      ~RawLog()
+      {
+        if (FILE* fp = std::fopen(path.c_str(), "w"))
+        {
+          for (size_t i = 0; i + 3 < v.size(); i += 4)
+            std::fprintf(fp, "%llu %.2f %.2f %u %u %u %u\n", v[i], v[i + 1] * 0.01, v[i + 2] * 0.01, static_cast<unsigned>(v[i + 3] >> 32) & 15u, static_cast<unsigned>(v[i + 3] >> 13) & 7u,
+                         static_cast<unsigned>(v[i + 3] >> 12) & 1u, static_cast<unsigned>(v[i + 3] >> 8) & 15u);
+          std::fclose(fp);
+        }
+      }
+    };
+    static RawLog log;
+    log.path = rawf;
+    for (uint32_t f = 0; f < cnt; f++)
+      if (t[32 * f + 13])
+      {
+        const unsigned long long rec[4] = {log.launch, t[32 * f], t[32 * f + 13], t[32 * f + 21]};
+        log.v.insert(log.v.end(), rec, rec + 4);
+      }
+    log.launch++;
+    HIPCHK(hipMemsetAsync(d_prof + 32 * static_cast<size_t>(s0), 0, sizeof(unsigned long long) * 32 * cnt, h->stream));
+    return VOFOD_OK;
+  }
   static const char* names[13] = {"bits", "prefix", "words", "rank-a/b", "rank-c", "emit", "extras", "probe", "adjacent", "far", "exact", "minima+stats", "labels"};  // (rank-a/b includes the counting pass: stamp 14 splits them)
   std::vector<std::pair<double, uint32_t>> byd;
   unsigned long long t0 = ~0ull, t1 = 0;
@@ -1454,7 +1487,8 @@ int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
       }
       std::sort(st.begin(), st.end());
       std::sort(en.begin(), en.end());
-      std::fprintf(fp, "}, \"start_us\": {\"median\": %.1f, \"max\": %.1f}, \"end_us\": {\"median\": %.1f, \"max\": %.1f}}\n", st[st.size() / 2], st.back(), en[en.size() / 2], en.back());
+      std::fprintf(fp, "}, \"start_us\": {\"median\": %.1f, \"max\": %.1f}, \"end_us\": {\"median\": %.1f, \"max\": %.1f}", st[st.size() / 2], st.back(), en[en.size() / 2], en.back());
+      std::fprintf(fp, "}\n");
       std::fclose(fp);
     }
   }
