@@ -591,6 +591,8 @@ def profile_pass(lib, det, scans, tfs, n_pts, V, F, V_far=0.0):
             # (the summary names a kernel as the profiler does: the launch aliases of the frame kernel are its two instantiations)
             alias = {"k_frame_lds_far": "k_frame_lds<1>", "k_frame_lds_full": "k_frame_lds<0>"}.get(dom, dom)
             key = alias if alias in tr else dom if dom in tr else dom.split("<")[0]  # (the summary drops non-numeric template arguments)
+            if key not in tr and dom.startswith("k_frame_lds") and "k_frame_lds" in tr:
+                key = "k_frame_lds"  # (round 5: two template arguments, <1, true> - the summary keeps the bare name; the profiled command launches the far instantiation only)
             if key in tr:
                 traffic = tr[key]["hbm_bytes_per_launch_corrected"]
                 traffic_note = f"profiles/{tr_file.name} (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, same command, same kernel sources)"

@@ -74,7 +74,7 @@ def test_far_view_on_warmed_maps(oracle, hip, sensor, vs, n_frames, warm):
         ref.load_apriori(np.zeros((0, 3), dtype=np.float32))
     sync_maps(dev, ref)
     frames = synth.bench_frames(scene, sensor, n_frames)
-    ga, gb, da = _check_far_view(ref, dev, [s.scan for s in frames], np.stack([s.tf for s in frames]), expect_close_first=bool(warm) or sensor == "os1-16")
+    ga, gb, da = _check_far_view(ref, dev, [s.scan for s in frames], np.stack([s.tf for s in frames]), expect_close_first=True if sensor == "os1-16" else (False if not warm else None))  # (12 warm-up scans leave an OS1-128 map with > 1 024 pure-far bricks per frame: either kernel)
     n_far = [int((g["clusters"]["is_close"] == 0).sum()) for g in ga]
     assert max(n_far) >= 2, n_far
     assert all(int(g["clusters"]["is_close"].sum()) >= 1 for g in ga)

@@ -16,6 +16,9 @@ def reduce(path, frames=256, skip=2):
     out["phases"] = {}
     for ph in rows[0]["phases"]:
         out["phases"][ph] = {q: round(sum(r["phases"][ph][q] for r in rows) / len(rows), 2) for q in ("mean", "median", "p90", "max")}
+    tl = [r for r in rows if "tail" in r]
+    if tl:  # k_tail_far's own stamps for the same frames (one wave per frame)
+        out["k_tail_far"] = {ph: {q: round(sum(r["tail"][ph][q] for r in tl) / len(tl), 2) for q in ("mean", "median", "p90", "max")} for ph in tl[0]["tail"]}
     return out
 
 

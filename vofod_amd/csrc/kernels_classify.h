@@ -87,10 +87,14 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
   uint32_t* visited = visited_all + static_cast<uint64_t>(slot) * EX_WORDS;  // clean on entry: every fill resets what it set
 
   auto map_read = [&](uint64_t li) -> float {
-    // the overlay is updated with atomics (L2); read it there too so this CU's L1 cannot serve a stale word
-    if (ep.no_update && ((__hip_atomic_load(&overlay[li >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (li & 63)) & 1ull))
-      return ep.frontier_value;
-    return map[li];
+    // the overlay is updated with atomics (L2); read it there too so this CU's L1 cannot serve a stale word.  Both loads are
+    // issued together (round 5: the map value used to be fetched only after the overlay word had come back - two round trips
+    // in every link of the fills' dependent chains; the map word of a valid cell can always be read)
+    const float mv = map[li];
+    if (!ep.no_update)
+      return mv;
+    const unsigned long long ow = __hip_atomic_load(&overlay[li >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((ow >> (li & 63)) & 1ull) ? ep.frontier_value : mv;
   };
 
   // ---- phase 1: classify_cluster's flood fills, job by job (vofod_nodelet.cpp:1694-1718)
@@ -142,21 +146,22 @@ __device__ __forceinline__ void explore_frame(const ExploreParams& ep, const Map
       if (job.R - 1 >= 1 && job.R - 1 <= 31)
       {
         const int len = job.R - 1;
-        for (int e = lane; e < 6 * 32; e += 64)
+        // (three voxels per lane; their loads go out together - the start voxel is an inner voxel of the map, a walk that leaves
+        // the map reads the start voxel's word instead and is marked blocked)
+        float wv[3];
+        bool win[3];
+        const uint64_t li0 = (static_cast<uint64_t>(oz) * mg.sy + oy) * mg.sx + ox;
+#pragma unroll
+        for (int u = 0; u < 3; u++)
         {
-          const int q = e >> 5, d = (e & 31) + 1;
-          uint8_t st = 0;  // 0 blocked, 1 unknown, 2 ground
-          if (d <= len)
-          {
-            const int ax = ox + (q == 0 ? d : q == 3 ? -d : 0), ay = oy + (q == 1 ? d : q == 4 ? -d : 0), az = oz + (q == 2 ? d : q == 5 ? -d : 0);
-            if (ax >= 0 && ax <= mg.sx - 1 && ay >= 0 && ay <= mg.sy - 1 && az >= 0 && az <= mg.sz - 1)
-            {
-              const float v = map_read((static_cast<uint64_t>(az) * mg.sy + ay) * mg.sx + ax);
-              st = v > ep.thr_ground ? 2 : (v > ep.thr_unknown ? 1 : 0);
-            }
-          }
-          s_walk[e] = st;
+          const int e = lane + 64 * u, q = e >> 5, d = (e & 31) + 1;
+          const int ax = ox + (q == 0 ? d : q == 3 ? -d : 0), ay = oy + (q == 1 ? d : q == 4 ? -d : 0), az = oz + (q == 2 ? d : q == 5 ? -d : 0);
+          win[u] = d <= len && ax >= 0 && ax <= mg.sx - 1 && ay >= 0 && ay <= mg.sy - 1 && az >= 0 && az <= mg.sz - 1;
+          wv[u] = map_read(win[u] ? (static_cast<uint64_t>(az) * mg.sy + ay) * mg.sx + ax : li0);
         }
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+          s_walk[lane + 64 * u] = !win[u] ? 0 : (wv[u] > ep.thr_ground ? 2 : (wv[u] > ep.thr_unknown ? 1 : 0));  // 0 blocked, 1 unknown, 2 ground
         wave_sync();
         bool walk_ok = false;
         if (lane < 6)

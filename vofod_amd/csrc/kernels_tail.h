@@ -34,6 +34,7 @@ constexpr int TAIL_WPB = TAIL_WPB_DEF;  // frames (waves) per workgroup of k_tai
 #endif
 using namespace vk;
 
+constexpr int TAIL_STAGE = 512;  // candidate members per frame whose centres k_tail_far keeps in LDS (6 KB per wave)
 constexpr int TP_THREADS = 256;
 constexpr int TP_MAXM = TAIL_MAXM;  // candidate members per frame
 constexpr int TP_MAXC = TAIL_MAXC;  // candidate clusters per frame (one lane each)
@@ -303,10 +304,11 @@ __global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const 
                                                 int* __restrict__ members_out, float* __restrict__ map, unsigned long long* __restrict__ overlay_all, uint32_t* __restrict__ stack_all,
                                                 uint32_t* __restrict__ explored_all, uint32_t* __restrict__ touched_all, uint32_t* __restrict__ ovl_list_all, uint32_t* __restrict__ ovl_count_all,
                                                 vc::ExploreResult* __restrict__ results, uint32_t* __restrict__ visited_all, FrameDets* __restrict__ dets, FrameDets* __restrict__ hout,
-                                                TailCluster* __restrict__ tailc)
+                                                TailCluster* __restrict__ tailc, unsigned long long* __restrict__ prof)
 {
   __shared__ uint8_t s_float_all[TAIL_WPB][TP_MAXC];
   __shared__ uint8_t s_walk_all[TAIL_WPB][6 * 32];
+  __shared__ float s_pts_all[TAIL_WPB][TAIL_STAGE][3];
   const uint32_t f = blockIdx.x * TAIL_WPB + (threadIdx.x >> 6);  // one wave per frame, TAIL_WPB frames per workgroup
   if (f >= g.n_frames)
     return;
@@ -314,6 +316,9 @@ __global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const 
   uint8_t* s_walk = s_walk_all[threadIdx.x >> 6];
   const FrameHdr h = hdrs[f];
   const int lane = threadIdx.x & 63;
+  // (diagnostics, VOFOD_LDS_PROF=2: slots 22 / 23 of the frame's stamps - start, then boxes | explore | end as 20-bit offsets in 10 ns)
+  const unsigned long long tp0 = prof ? wall_clock64() : 0ull;
+  unsigned long long tp1 = 0ull, tp2 = 0ull;
   FrameDets& out = dets[f];
   uint32_t fallback = 0;
   const bool ok = h.status == VOFOD_OK;
@@ -345,6 +350,22 @@ __global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const 
     }
     m_begin = incl - m_count;
   }
+  // Round 5: the candidates' member centres are fetched ONCE, by all 64 lanes together, into the wave's own LDS; boxes_of_n walks
+  // a cluster's members three times (mean, covariance, OBB extents), one lane per cluster, and every visit was two dependent
+  // global loads (member list -> voxel record): ~34 us per frame of nothing but latency.  Members beyond the staging area (a
+  // frame with more than TAIL_STAGE candidate members) are read from global memory as before - same values either way.
+  float (*s_pts)[3] = s_pts_all[threadIdx.x >> 6];
+  {
+    const uint32_t total = min(static_cast<uint32_t>(__shfl(m_begin + m_count, 63)), static_cast<uint32_t>(TAIL_STAGE));
+    for (uint32_t i = lane; i < total; i += 64)
+    {
+      const float4 q = va.pts[cands[i].v];
+      s_pts[i][0] = q.x;
+      s_pts[i][1] = q.y;
+      s_pts[i][2] = q.z;
+    }
+    vc::wave_sync();
+  }
   bool wants_job = false;
   vc::ExploreJob job{};
   TailCluster tc{};
@@ -354,7 +375,15 @@ __global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const 
     tc.root = rec.root;
     tc.n_members = m_count;
     auto get = [&](size_t i, float p[3]) {
-      const float4 q = va.pts[cands[m_begin + i].v];
+      const uint32_t k = m_begin + static_cast<uint32_t>(i);
+      if (k < static_cast<uint32_t>(TAIL_STAGE))
+      {
+        p[0] = s_pts[k][0];
+        p[1] = s_pts[k][1];
+        p[2] = s_pts[k][2];
+        return;
+      }
+      const float4 q = va.pts[cands[k].v];
       p[0] = q.x;
       p[1] = q.y;
       p[2] = q.z;
@@ -450,9 +479,13 @@ __global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const 
   }
   __threadfence_block();
   vc::wave_sync();  // the jobs and their members' map voxels are written: the wave reads them back
+  if (prof)
+    tp1 = wall_clock64();
   vc::explore_frame(ep, mg, jobs, jb, jb + n_jobs, members_out, map, overlay_all, stack_all, explored_all, touched_all, ovl_list_all, ovl_count_all, results, visited_all, f, s_float, s_walk);
   __threadfence_block();
   vc::wave_sync();
+  if (prof)
+    tp2 = wall_clock64();
   // the floating clusters (extractDetections :843-846) in cluster order, as k_tail_finish
   bool det = false, bad = false;
   double conf = 0.0;
@@ -499,6 +532,13 @@ __global__ TAIL_OCC_ATTR __launch_bounds__(64 * TAIL_WPB) void k_tail_far(const 
       hout[f].fallback = fb;
       hout[f].status = h.status;
       hout[f].n_jobs = n_jobs;
+    }
+    if (prof)
+    {
+      const unsigned long long te = wall_clock64();
+      auto d20 = [&](unsigned long long t) { return (t - tp0) > 0xfffffull ? 0xfffffull : (t - tp0); };
+      prof[static_cast<size_t>(f) * 32 + 22] = tp0;
+      prof[static_cast<size_t>(f) * 32 + 23] = d20(tp1) | (d20(tp2) << 20) | (d20(te) << 40) | (static_cast<unsigned long long>(n_jobs > 15u ? 15u : n_jobs) << 60);
     }
   }
 }

@@ -1488,6 +1488,40 @@ int print_frame_prof(vofod_handle* h, uint32_t s0, uint32_t cnt, bool sync)
       std::sort(st.begin(), st.end());
       std::sort(en.begin(), en.end());
       std::fprintf(fp, "}, \"start_us\": {\"median\": %.1f, \"max\": %.1f}, \"end_us\": {\"median\": %.1f, \"max\": %.1f}", st[st.size() / 2], st.back(), en[en.size() / 2], en.back());
+      {
+        // the classification tail of the same frames (k_tail_far's stamps): boxes + gates, flood fills, records; and how long after
+        // the frame's own end its tail started
+        std::vector<double> bx, ex, fi, to, lag;
+        for (auto& b : byd)
+        {
+          const unsigned long long a0 = t[32 * b.second + 22], pk = t[32 * b.second + 23];
+          if (!a0)
+            continue;
+          const double d1 = (pk & 0xfffffull) * 0.01, d2 = ((pk >> 20) & 0xfffffull) * 0.01, d3 = ((pk >> 40) & 0xfffffull) * 0.01;
+          bx.push_back(d1);
+          ex.push_back(d2 - d1);
+          fi.push_back(d3 - d2);
+          to.push_back(d3);
+          lag.push_back((static_cast<double>(a0) - static_cast<double>(t[32 * b.second + 13])) * 0.01);
+        }
+        if (!to.empty())
+        {
+          auto q = [&](std::vector<double>& v, const char* name, bool last) {
+            std::sort(v.begin(), v.end());
+            double m = 0;
+            for (double x : v)
+              m += x / v.size();
+            std::fprintf(fp, "\"%s\": {\"mean\": %.2f, \"median\": %.2f, \"p90\": %.2f, \"max\": %.2f}%s", name, m, v[v.size() / 2], v[v.size() * 9 / 10], v.back(), last ? "" : ", ");
+          };
+          std::fprintf(fp, ", \"tail\": {");
+          q(bx, "boxes_gates", false);
+          q(ex, "flood_fills", false);
+          q(fi, "records", false);
+          q(to, "total", false);
+          q(lag, "start_after_frame_end", true);
+          std::fprintf(fp, "}");
+        }
+      }
       std::fprintf(fp, "}\n");
       std::fclose(fp);
     }
@@ -2270,7 +2304,8 @@ int process_frames(vofod_handle* h, Workspace& ws, FramesPhase phase, const vofo
     else if ((ws.far_ran && ws.close_first == 1) || far_single)
       // close-first frames: ordered lists from the frame kernel (or k_far_final), the whole tail in one kernel of one wave per frame
       KLAUNCH(h, vtd::k_tail_far, dim3((n + vtd::TAIL_WPB - 1) / vtd::TAIL_WPB), dim3(64 * vtd::TAIL_WPB), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, ep, eb.d_jobs, eb.d_members, h->d_map, eb.d_overlay, eb.d_stack, eb.d_explored, eb.d_touched,
-              eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited, ws.d_dets, ws.h_dets_dev, far_single ? ws.d_tailc : static_cast<vtd::TailCluster*>(nullptr));
+              eb.d_ovl_list, eb.d_ovl_count, eb.d_results, eb.d_visited, ws.d_dets, ws.h_dets_dev, far_single ? ws.d_tailc : static_cast<vtd::TailCluster*>(nullptr),
+              (ws.prof_deferred && h->d_prof_ccl && !far_single) ? h->d_prof_ccl + 32 * static_cast<size_t>(ws.prof_slot0) : static_cast<unsigned long long*>(nullptr));
     else
     {
       KLAUNCH(h, vtd::k_tail_prep, dim3(n), dim3(vtd::TP_THREADS), g, ws.d_hdrs, ws.d_args, ws.d_table, ws.d_cand, ws.va, h->mg, tp, eb.d_jobs, ws.d_job_be, ws.d_job_be + ws.F, eb.d_members, ws.d_tailc,
