@@ -443,3 +443,57 @@ def test_whole_scan_raycast_map_is_segment_voxel_geometry(oracle):
     # the gates were really exercised: dropping either changes the map
     assert int(((np.asarray(s.intensity) < 250.0)).sum()) > 1000 and int(((mask == 0) & (np.asarray(s.range) == 0)).sum()) > 100
     det.close()
+
+
+@pytest.mark.parametrize("new_rule", [1, 0])
+def test_raycast_update_sweep_is_the_voxelwise_formula(oracle, new_rule):
+    """The other half of raycast_cloud (vofod_nodelet.cpp:1540-1604) on a whole map, against the formula written out in numpy: a
+    voxel changes iff its flag is unmarked and a ray passed; new rule w1 = 2^(-its_diff * coef / (sqrt(3) vs) * r) with the power
+    taken in double and rounded to float, old rule w1 = clamp((1 - coef * sqrt(r / max))^its_diff, 0, 1); map <- w1 map + (1 - w1)
+    ray_score in float; flags cleared.  Two detection iterations pass between begin and finish (its_diff = 2), the second scan marks
+    voxels of its own.  Elementwise, so the tolerance is one float rounding of the product (1e-6 relative): the compiler may or
+    may not keep `w1*mapval + w2*score` unfused - the oracle is built with -ffp-contract=off, as the product is."""
+    from vofod_amd.detector import VoFOD, default_params
+
+    sensor, vs = "os1-16", 0.5
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    dp.raycast__new_update_rule = new_rule
+    det = VoFOD(oracle, sp, dp)
+    synth.seed_ground(det)
+    scene = synth.make_scene(21, n_targets=2)
+    s0, s1, s2 = synth.scan_sequence(scene, sensor, 3, seed0=300)
+    det.process_scan(s0.scan, s0.tf)
+    its0 = det.status().detection_its
+    assert det.raycast_begin(s0.scan, s0.tf) == capi.OK
+    det.process_scan(s1.scan, s1.tf)
+    det.process_scan(s2.scan, s2.tf)
+    its_diff = np.float32(det.status().detection_its - its0)
+    assert its_diff == 2
+    m, fl, r = (det.read_map(k).astype(np.float32).reshape(-1) for k in (capi.MAP_VOXELS, capi.MAP_FLAGS, capi.MAP_RAYCAST))
+    assert det.raycast_finish() == capi.OK
+    got = det.read_map(capi.MAP_VOXELS).reshape(-1)
+    upd = (fl == 0) & (r > 0)
+    # both branches of the condition occur (rays end one voxel in front of their hit, :1457: only a few marked voxels see a ray)
+    assert upd.sum() > 10_000 and (fl != 0).sum() > 100 and ((fl != 0) & (r > 0)).sum() >= 1
+    score, coef = np.float32(dp.voxel_map__scores__ray), np.float32(dp.raycast__weight_coefficient)
+    if new_rule:
+        wf = np.float32(coef / np.float32(np.float32(np.sqrt(3.0)) * np.float32(vs)))  # std::sqrt(3) is a double, times a float: rounded once
+        n_int = wf * r[upd]
+        w1 = np.exp2(-(its_diff.astype(np.float64) * n_int.astype(np.float64))).astype(np.float32)
+    else:
+        mx = r.max()
+        ws = coef * np.sqrt(r[upd] / mx, dtype=np.float32)
+        w1 = np.clip(np.power((np.float32(1.0) - ws).astype(np.float64), np.float64(its_diff)).astype(np.float32), np.float32(0), np.float32(1))
+    want = m.copy()
+    with np.errstate(invalid="ignore"):
+        want[upd] = w1 * m[upd] + (np.float32(1.0) - w1) * score
+    fin = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), fin)
+    np.testing.assert_array_equal(got[~upd], m[~upd])  # untouched elsewhere, bit for bit
+    np.testing.assert_allclose(got[fin], want[fin], rtol=2e-6, atol=1e-6)
+    assert not det.read_map(capi.MAP_FLAGS).any()  # m_voxel_flags.clear() :1601
+    det.close()
