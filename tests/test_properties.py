@@ -497,3 +497,143 @@ def test_raycast_update_sweep_is_the_voxelwise_formula(oracle, new_rule):
     np.testing.assert_allclose(got[fin], want[fin], rtol=2e-6, atol=1e-6)
     assert not det.read_map(capi.MAP_FLAGS).any()  # m_voxel_flags.clear() :1601
     det.close()
+
+
+@pytest.mark.parametrize("sensor,vs", [("os1-16", 0.5), ("os1-128", 0.25)])
+def test_map_update_of_a_scan_is_the_voxelwise_formula(oracle, sensor, vs):
+    """updateVMaps / updateVoxel (vofod_nodelet.cpp:777-815, called at :946-948) for a whole scan, from the scan's own debug output:
+    every voxel of the weighted cloud lands in map cell floor((p - offset) / vs) (float), a voxel of a close cluster pulls the cell
+    towards scores/point and flags it 2, a voxel of a far cluster towards scores/unknown and flags it 3, with w = 2^-min(weight, 63)
+    (`1lu << clamp(range, 0, 63)`, :789); nothing else of the map changes.  No latch is set on this map, so classification writes no
+    frontiers (:1694) and the update is all that happens.  Bit-exact: one product and one sum per cell, no contraction."""
+    from vofod_amd.detector import VoFOD, default_params
+
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    det = VoFOD(oracle, sp, dp)
+    synth.seed_ground(det)
+    scene = synth.make_scene(21, n_targets=2)
+    s = synth.scan_sequence(scene, sensor, 1, seed0=300)[0]
+    m0, f0 = det.read_map(capi.MAP_VOXELS).reshape(-1).copy(), det.read_map(capi.MAP_FLAGS).reshape(-1).copy()
+    dets, g = det.process_scan(s.scan, s.tf, debug=True)
+    st = det.status()
+    assert not (st.background_pts_sufficient and st.sure_background_sufficient) and len(dets) == 0
+    pts, lab, cl = g["weighted"], g["labels"], g["clusters"]
+    close_of_root = dict(zip(cl["first_member"].tolist(), cl["is_close"].tolist()))
+    is_close = np.array([close_of_root[int(r)] for r in lab], dtype=bool)
+    assert is_close.any() and (~is_close).any()
+    off = np.array(det.map_offset, dtype=np.float32)
+    sx, sy, sz = (int(x) for x in det.map_size)
+    inv = np.float32(1.0) / np.float32(vs)
+    c = np.stack([np.floor((pts[k] - off[a]) * inv) for a, k in enumerate("xyz")], axis=1).astype(np.int64)
+    assert ((c >= 0) & (c < np.array([sx, sy, sz]))).all()
+    li = (c[:, 2] * sy + c[:, 1]) * sx + c[:, 0]
+    assert len(np.unique(li)) == len(li)  # the grid is aligned to the map: one voxel per cell (SURVEY Q2)
+    wgt = (np.float32(1.0) / np.exp2(np.minimum(pts["range"], 63).astype(np.float64))).astype(np.float32)
+    score = np.where(is_close, np.float32(dp.voxel_map__scores__point), np.float32(dp.voxel_map__scores__unknown)).astype(np.float32)
+    want_m, want_f = m0.copy(), f0.copy()
+    want_m[li] = wgt * m0[li] + (np.float32(1.0) - wgt) * score
+    want_f[li] = np.where(is_close, np.float32(2.0), np.float32(3.0))  # m_vflags_point / m_vflags_unknown, :2335-2337
+    np.testing.assert_array_equal(det.read_map(capi.MAP_VOXELS).reshape(-1).view(np.uint32), want_m.view(np.uint32))
+    np.testing.assert_array_equal(det.read_map(capi.MAP_FLAGS).reshape(-1), want_f)
+    det.close()
+
+
+@pytest.mark.parametrize("sensor,vs,seed", [("os1-16", 0.5, 300), ("os1-128", 0.25, 301)])
+def test_filter_and_transform_of_a_scan_against_numpy_crops(oracle, sensor, vs, seed):
+    """filterAndTransform (vofod_nodelet.cpp:621-668) inside process_scan, stage by stage in numpy float32: CropBox 1 removes the
+    points INSIDE the exclude box (sensor frame, closed box: offset +- size / 2, the z offset being the box's bottom, :204), the
+    rigid transform in PCL's association c0 x + (c1 y + (c2 z + c3)), CropBox 2 keeps the points inside the closed operation area
+    (world frame, :212).  The survivors, handed to the stand-alone weighted grid (itself pinned against np.unique by
+    test_weighted_grid_against_numpy_unique) with the map's alignment (:664), must give the scan's weighted cloud bit for bit, and
+    their number is `n_input_after_crop`."""
+    from vofod_amd.detector import VoFOD, default_params
+
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    det = VoFOD(oracle, sp, dp)
+    synth.seed_ground(det)
+    scene = synth.make_scene(21, n_targets=2)
+    s = synth.scan_sequence(scene, sensor, 1, seed0=seed)[0]
+    _, g = det.process_scan(s.scan, s.tf, flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+    f32 = np.float32
+    x, y, z = (np.asarray(a, dtype=f32) for a in (s.x, s.y, s.z))
+
+    def box(off, size):
+        o, sz = np.array(list(off), dtype=f32), np.array(list(size), dtype=f32)
+        c = o.copy()
+        c[2] = o[2] + sz[2] / f32(2)  # the yaml's z offset is the bottom of the box (:204, :212)
+        return c - sz / f32(2), c + sz / f32(2)
+
+    lo, hi = box(sp.exclude_offset, sp.exclude_size)
+    inside_ex = (x >= lo[0]) & (x <= hi[0]) & (y >= lo[1]) & (y <= hi[1]) & (z >= lo[2]) & (z <= hi[2])
+    keep1 = ~inside_ex & np.isfinite(x) & np.isfinite(y) & np.isfinite(z)
+    tf = np.asarray(s.tf, dtype=f32).reshape(3, 4)
+    q = [tf[r, 0] * x + (tf[r, 1] * y + (tf[r, 2] * z + tf[r, 3])) for r in range(3)]  # every operation rounded to float
+    lo, hi = box(sp.oparea_offset, sp.oparea_size)
+    keep2 = keep1 & (q[0] >= lo[0]) & (q[0] <= hi[0]) & (q[1] >= lo[1]) & (q[1] <= hi[1]) & (q[2] >= lo[2]) & (q[2] <= hi[2])
+    assert 0.1 * x.size < keep2.sum() < 0.9 * x.size and inside_ex.sum() > 0
+    assert int(keep2.sum()) == g["n_input_after_crop"]
+    align = np.array(det.map_offset, dtype=f32) + f32(vs) / f32(2)  # idxToCoord(0, 0, 0): the centre of map voxel 0 (:664)
+    pts, keys, grid, _ = voxel_grid_weighted(oracle, q[0][keep2], q[1][keep2], q[2][keep2], vs, align)
+    np.testing.assert_array_equal(pts.view(np.uint32), g["weighted"].view(np.uint32))
+    det.close()
+
+
+def test_detection_records_against_the_formulas_in_numpy(oracle):
+    """extractDetections (vofod_nodelet.cpp:834-879) from a scan's own debug output and the map the call leaves behind: one record
+    per cluster classified MAV, in cluster order; n_points; position = the OBB centre; covariance = sqrt(dist) sigma I; the
+    uncertainty sum over the map box of the cluster's AABB inflated by two voxels (getSubmapCopy, voxel_map.cpp:550-559), the
+    cluster's own cells counted as free air, divided by the number of points, confidence = 1 / exp(u) as a float; the detection
+    probability from the sensor's ray resolutions.  Double arithmetic on both sides: 1e-9 relative (the order of the double sum)."""
+    from vofod_amd.detector import VoFOD, default_params
+
+    sensor, vs = "os1-128", 0.5
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    det = VoFOD(oracle, sp, dp)
+    scene = synth.make_scene(21, n_targets=3)
+    det.load_apriori(synth.apriori_points(scene, vs))
+    off = np.array(det.map_offset, dtype=np.float32)
+    sx, sy, sz = (int(x) for x in det.map_size)
+    ray_score = float(dp.voxel_map__scores__ray)
+    n_checked = 0
+    for s in synth.scan_sequence(scene, sensor, 6, seed0=300):
+        dets, g = det.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST, debug=True)
+        m = det.read_map(capi.MAP_VOXELS).reshape(sz, sy, sx).astype(np.float64)  # x fastest (voxel_map.cpp:81)
+        cl, lab, pts = g["clusters"], g["labels"], g["weighted"]
+        mav = cl[cl["cclass"] == capi.CLASS_MAV]
+        assert len(dets) == len(mav)
+        tpos = np.asarray(s.tf, dtype=np.float32).reshape(3, 4)[:, 3]
+        for d, c in zip(dets, mav):  # cluster order
+            mem = pts[lab == c["first_member"]]
+            assert d["n_points"] == len(mem) == c["n_points"]
+            np.testing.assert_array_equal(d["position"].astype(np.float32), c["obb_center"])
+            dv = (tpos - c["obb_center"]).astype(np.float32)
+            dist = float(np.sqrt(np.float32(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2])))  # Eigen's float norm(), widened
+            np.testing.assert_allclose(np.asarray(d["covariance"]).reshape(3, 3), np.sqrt(dist) * float(dp.output__position_sigma) * np.eye(3), rtol=1e-6)
+            cell = lambda p: np.floor((np.asarray(p, dtype=np.float32) - off) * np.float32(1.0 / vs)).astype(np.int64)
+            mn = np.array([mem[k].min() for k in "xyz"], dtype=np.float32)
+            mx = np.array([mem[k].max() for k in "xyz"], dtype=np.float32)
+            lo = np.clip(cell(mn) - 2, 0, [sx - 1, sy - 1, sz - 1])
+            hi = np.clip(cell(mx) + 2, 0, [sx - 1, sy - 1, sz - 1])
+            sub = m[lo[2] : hi[2] + 1, lo[1] : hi[1] + 1, lo[0] : hi[0] + 1].copy()
+            mc = np.stack([cell(np.array([p["x"], p["y"], p["z"]])) for p in mem]) - lo
+            sub[mc[:, 2], mc[:, 1], mc[:, 0]] = np.float64(np.float32(ray_score))  # the cluster's own voxels count as free air (:853-857)
+            u = float((1.0 - sub / ray_score).sum()) / len(mem)
+            np.testing.assert_allclose(d["confidence"], np.float32(1.0 / np.exp(u)), rtol=2e-6)
+            vres, hres = float(sp.sensor_vfov) / h, 2 * np.pi / w
+            pdet = min(np.arctan(1.0 / dist) / (vres * int(dp.classification__min_points)), 1.0) * min(np.arctan(1.0 / dist) / hres, 1.0)
+            np.testing.assert_allclose(d["detection_probability"], pdet, rtol=1e-9)
+            n_checked += 1
+    assert n_checked >= 2
+    det.close()
