@@ -637,3 +637,88 @@ def test_detection_records_against_the_formulas_in_numpy(oracle):
             n_checked += 1
     assert n_checked >= 2
     det.close()
+
+
+def test_classification_of_a_scan_against_scipy_fills_in_cluster_order(oracle):
+    """classify_cluster over all far clusters of a scan (vofod_nodelet.cpp:1648-1730, called in cluster order at :961): the three
+    gates on the scan's own boxes, then - both latches set - exploreToGround from every member in turn on the map AS THE EARLIER
+    FILLS LEFT IT: a connected member makes the cluster UNKNOWN and ends its walk, an unconnected one turns the unknown voxels it
+    explored into frontiers (:1712-1715).  The fill is scipy's component of the unknown voxels inside the Manhattan ball (the
+    statement test_explore_to_ground_against_scipy_labelling pins on random maps), the map before classification is the pre-scan map
+    under the update formula of test_map_update_of_a_scan_is_the_voxelwise_formula.  Classes of all far clusters and the map the
+    call leaves behind - frontier voxels included - must be the oracle's, bit for bit."""
+    from scipy import ndimage
+
+    from vofod_amd.detector import VoFOD, default_params
+
+    sensor, vs = "os1-128", 0.5
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    det = VoFOD(oracle, sp, dp)
+    scene = synth.make_scene(21, n_targets=3)
+    det.load_apriori(synth.apriori_points(scene, vs))
+    scans = synth.scan_sequence(scene, sensor, 8, seed0=300)
+    for s in scans[:6]:  # carve the free space around the targets (the raycast role), unchecked
+        det.process_scan(s.scan, s.tf, flags=capi.SCAN_AUTO_RAYCAST)
+    off = np.array(det.map_offset, dtype=np.float32)
+    sx, sy, sz = (int(x) for x in det.map_size)
+    thr_f, thr_g = np.float32(dp.voxel_map__thresholds__frontiers), np.float32(dp.voxel_map__thresholds__new_obstacles)
+    seen = {capi.CLASS_MAV: 0, capi.CLASS_UNKNOWN: 0, capi.CLASS_INVALID: 0}
+    n_frontier = 0
+    for s in scans[6:]:
+        m = det.read_map(capi.MAP_VOXELS).reshape(sz, sy, sx).copy()
+        _, g = det.process_scan(s.scan, s.tf, debug=True)
+        st = det.status()
+        assert st.background_pts_sufficient and st.sure_background_sufficient
+        pts, lab, cl = g["weighted"], g["labels"], g["clusters"]
+        cell = np.stack([np.floor((pts[k] - off[a]) * np.float32(1.0 / vs)) for a, k in enumerate("xyz")], axis=1).astype(np.int64)
+        close_of_root = dict(zip(cl["first_member"].tolist(), cl["is_close"].tolist()))
+        is_close = np.array([close_of_root[int(r)] for r in lab], dtype=bool)
+        wgt = (np.float32(1.0) / np.exp2(np.minimum(pts["range"], 63).astype(np.float64))).astype(np.float32)
+        score = np.where(is_close, np.float32(dp.voxel_map__scores__point), np.float32(dp.voxel_map__scores__unknown)).astype(np.float32)
+        iz, iy, ix = cell[:, 2], cell[:, 1], cell[:, 0]
+        m[iz, iy, ix] = wgt * m[iz, iy, ix] + (np.float32(1.0) - wgt) * score  # updateVMaps :946-948
+        tpos = np.asarray(s.tf, dtype=np.float32).reshape(3, 4)[:, 3]
+        for c in cl[cl["is_close"] == 0]:  # far clusters, in cluster order
+            want = capi.CLASS_INVALID
+            members = np.flatnonzero(lab == c["first_member"])  # ascending voxel index = the order of cluster_indices
+            dv = (tpos - c["obb_center"]).astype(np.float32)
+            dist = float(np.sqrt(np.float32(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2])))
+            if len(members) >= int(dp.classification__min_points) and not dist > float(dp.classification__max_distance) and not float(c["obb_size"]) > float(dp.classification__max_size):
+                R = int((float(c["obb_size"]) + float(dp.classification__max_explore_distance)) / float(np.float32(vs)))
+                floating = True
+                for v in members:
+                    o = cell[v]
+                    if (o <= 0).any() or (o >= np.array([sx - 1, sy - 1, sz - 1])).any():  # voxel_map.cpp:408-411
+                        floating = False
+                        break
+                    lo = np.maximum(o - (R + 1), 0)
+                    hi = np.minimum(o + (R + 1), [sx - 1, sy - 1, sz - 1])
+                    box = m[lo[2] : hi[2] + 1, lo[1] : hi[1] + 1, lo[0] : hi[0] + 1]
+                    zz, yy, xx = np.meshgrid(*(np.arange(lo[a], hi[a] + 1) for a in (2, 1, 0)), indexing="ij")
+                    manh = np.abs(xx - o[0]) + np.abs(yy - o[1]) + np.abs(zz - o[2])
+                    ball, ground = manh <= R, box > thr_g
+                    unknown = (box > thr_f) & ~ground
+                    so = (o[2] - lo[2], o[1] - lo[1], o[0] - lo[0])
+                    if ground[so]:
+                        floating = False
+                        break
+                    if not unknown[so]:
+                        continue  # popped, neither ground nor unknown: nothing explored
+                    labels, _ = ndimage.label(unknown & ball)
+                    comp = labels == labels[so]
+                    popped = ndimage.binary_dilation(comp) & ball
+                    if (popped & ground).any() or (comp & (manh == R - 1)).any():
+                        floating = False
+                        break
+                    box[comp] = thr_f  # (a view: the frontiers stay for the members and clusters that follow)
+                    n_frontier += int(comp.sum())
+                want = capi.CLASS_MAV if floating else capi.CLASS_UNKNOWN
+            assert int(c["cclass"]) == want, (int(c["first_member"]), int(c["n_points"]), int(c["cclass"]), want)
+            seen[want] += 1
+        np.testing.assert_array_equal(det.read_map(capi.MAP_VOXELS).reshape(sz, sy, sx).view(np.uint32), m.view(np.uint32))
+    assert seen[capi.CLASS_MAV] >= 2 and seen[capi.CLASS_UNKNOWN] >= 1 and n_frontier > 0, (seen, n_frontier)
+    det.close()
