@@ -722,3 +722,64 @@ def test_classification_of_a_scan_against_scipy_fills_in_cluster_order(oracle):
         np.testing.assert_array_equal(det.read_map(capi.MAP_VOXELS).reshape(sz, sy, sx).view(np.uint32), m.view(np.uint32))
     assert seen[capi.CLASS_MAV] >= 2 and seen[capi.CLASS_UNKNOWN] >= 1 and n_frontier > 0, (seen, n_frontier)
     det.close()
+
+
+@pytest.mark.parametrize("sensor,vs", [("os1-16", 0.5), ("os1-128", 0.25)])
+def test_close_far_split_and_clusters_of_a_scan_against_scipy(oracle, sensor, vs):
+    """clusterCloud + findCloseFarClusters of a whole scan (vofod_nodelet.cpp:689-750) from its weighted cloud alone: the clusters
+    are the connected components of the graph `d^2 < tol^2` over the voxel centres (FLANN's float expression; scipy's sparse
+    components here), a cluster is close iff ANY member's cell lies in the occupancy image `m > new_obstacles` of the map BEFORE the
+    update, dilated by hasCloseTo's stencil (half-open cube, truncated integer norm: the structuring element of
+    test_has_close_to_is_a_dilation_of_the_occupancy_image); `n_bg_voxels` = nVoxelsOver of that map.  Labels (smallest member),
+    sizes, close flags: bit for bit."""
+    from scipy import ndimage, sparse
+    from scipy.sparse import csgraph
+    from scipy.spatial import cKDTree
+
+    from vofod_amd.detector import VoFOD, default_params
+
+    h, w, vfov_deg, _ = synth.SENSORS[sensor]
+    sp, dp = default_params(oracle)
+    sp.voxel_size = vs
+    sp.sensor_hrays, sp.sensor_vrays = w, h
+    sp.sensor_vfov = np.float32(np.deg2rad(vfov_deg))
+    det = VoFOD(oracle, sp, dp)
+    scene = synth.make_scene(21, n_targets=3)
+    synth.warm_map(det, scene, sensor, 4)
+    s = synth.scan_sequence(scene, sensor, 1, seed0=555)[0]
+    sx, sy, sz = (int(x) for x in det.map_size)
+    m = det.read_map(capi.MAP_VOXELS).reshape(sz, sy, sx).copy()
+    _, g = det.process_scan(s.scan, s.tf, flags=capi.SCAN_NO_MAP_UPDATE, debug=True)
+    pts, lab, cl = g["weighted"], g["labels"], g["clusters"]
+    P = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32)
+    tol = np.float32(dp.ground_points_max_distance)
+    # candidate pairs from a k-d tree with a margin, the decision by the float expression itself (strict <)
+    pairs = cKDTree(P.astype(np.float64)).query_pairs(float(tol) * 1.001, output_type="ndarray")
+    d = P[pairs[:, 0]] - P[pairs[:, 1]]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]  # L2_Simple accumulates in float, axis by axis
+    keep = d2 < tol * tol
+    n = len(P)
+    _, comp = csgraph.connected_components(sparse.coo_matrix((np.ones(int(keep.sum())), (pairs[keep, 0], pairs[keep, 1])), shape=(n, n)), directed=False)
+    first = np.full(comp.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first, comp, np.arange(n))
+    np.testing.assert_array_equal(lab, first[comp].astype(lab.dtype))  # label = smallest member
+    # close / far
+    thr = np.float32(dp.voxel_map__thresholds__new_obstacles)
+    occ = m > thr
+    assert g["n_bg_voxels"] == int(occ.sum())
+    mdi = np.float32(dp.ground_points_max_distance) * np.float32(np.float32(1.0) / np.float32(vs))
+    dd = int(np.ceil(mdi))
+    o = np.arange(-dd, dd + 1)
+    oz, oy, ox = np.meshgrid(o, o, o, indexing="ij")
+    S = (np.floor(np.sqrt((ox * ox + oy * oy + oz * oz).astype(np.float64))).astype(np.float32) <= mdi) & (ox < dd) & (oy < dd) & (oz < dd)
+    close_img = ndimage.binary_dilation(occ, structure=S[::-1, ::-1, ::-1])
+    off = np.array(det.map_offset, dtype=np.float32)
+    c = np.stack([np.floor((pts[k] - off[a]) * np.float32(1.0 / vs)) for a, k in enumerate("xyz")], axis=1).astype(np.int64)
+    vox_close = close_img[c[:, 2], c[:, 1], c[:, 0]]
+    want_close = np.zeros(comp.max() + 1, dtype=bool)
+    np.logical_or.at(want_close, comp, vox_close)
+    roots = cl["first_member"].astype(np.int64)
+    np.testing.assert_array_equal(cl["is_close"].astype(bool), want_close[comp[roots]])
+    np.testing.assert_array_equal(cl["n_points"], np.bincount(comp, minlength=comp.max() + 1)[comp[roots]])
+    assert len(cl) == comp.max() + 1 and want_close.any() and (~want_close).any()
+    det.close()
