@@ -783,3 +783,102 @@ def test_close_far_split_and_clusters_of_a_scan_against_scipy(oracle, sensor, vs
     np.testing.assert_array_equal(cl["n_points"], np.bincount(comp, minlength=comp.max() + 1)[comp[roots]])
     assert len(cl) == comp.max() + 1 and want_close.any() and (~want_close).any()
     det.close()
+
+
+@pytest.mark.parametrize("seed,max_bg", [(1, 0.8), (2, 0.8), (3, 1.6), (4, 2.2), (5, 0.8)])
+def test_sepclusters_role_against_numpy(oracle, seed, max_bg):
+    """updateSeparatedBGClusters (vofod_nodelet.cpp:1126-1277) on random maps, restated in numpy from the cited lines:
+    voxelsAsVoxelPC in x-outer / z-inner order with voxel INDICES as coordinates (voxel_map.cpp:186-211); VoxelGridCounted at leaf
+    max(ceil(d / vs) - 1, 0) (voxel_grid_counted.cpp:58-213, no alignment) whose `range` counts the sure voxels among the INPUT
+    positions [first, last) of the SORTED run (Q1: positions of one order applied to the other); Euclidean clusters at tolerance
+    ceil(d / vs), strict; a cluster is sure when its ranges sum to min_sure_points; without any sure cluster the latch goes off and
+    nothing changes; otherwise every voxel within the truncated-norm stencil of every down-sampled point (cast<int>) of every unsure
+    cluster is pulled half-way to scores/ray, once per (point, offset) pair.  Latch and map bit for bit."""
+    from scipy import sparse
+    from scipy.sparse import csgraph
+    from scipy.spatial import cKDTree
+
+    from vofod_amd.detector import VoFOD, default_params
+
+    f32 = np.float32
+    sp, dp = default_params(oracle)
+    vs = 0.5
+    sp.voxel_size = vs
+    sp.oparea_offset[:] = (10.0, 10.0, 0.0)
+    sp.oparea_size[:] = (20.0, 20.0, 10.0)
+    sp.sensor_hrays, sp.sensor_vrays = 8, 2
+    dp.sepclusters__max_bg_distance = max_bg
+    det = VoFOD(oracle, sp, dp)
+    sx, sy, sz = (int(x) for x in det.map_size)
+    rng = np.random.default_rng(seed)
+    thr_new, thr_sure = f32(dp.voxel_map__thresholds__new_obstacles), f32(dp.voxel_map__thresholds__sure_obstacles)
+    air = f32(-1000.0)
+    m = np.full((sz, sy, sx), air, dtype=f32)
+    # a ground sheet of sure voxels with a few unsure holes, islands of unsure voxels in the air, one small island of sure ones
+    if seed != 5:  # (seed 5: no sheet - no cluster collects min_sure_points sure voxels, the latch goes off, the map stays)
+        m[1, 3 : sy - 3, 3 : sx - 3] = f32(5.0)
+        holes = rng.random((sy - 6, sx - 6)) < 0.1
+        m[1, 3 : sy - 3, 3 : sx - 3][holes] = f32(-150.0)
+    for _ in range(int(rng.integers(4, 9))):
+        c = rng.integers([6, 6, 8], [sx - 6, sy - 6, sz - 3])
+        for _ in range(int(rng.integers(1, 7))):
+            q = c + rng.integers(-1, 2, 3)
+            m[q[2], q[1], q[0]] = f32(rng.choice([-150.0, -200.0, 5.0], p=[0.5, 0.3, 0.2]))
+    assert thr_new < f32(-200.0) and f32(-150.0) <= thr_sure < f32(5.0)
+    det.write_map(capi.MAP_VOXELS, m)
+    st, sure = det.sepclusters_begin(allow=(capi.ERR_EMPTY,))
+    assert st == capi.OK
+    if sure:
+        assert det.sepclusters_finish() == capi.OK
+    got = det.read_map(capi.MAP_VOXELS).reshape(sz, sy, sx)
+
+    # ---- the same in numpy
+    mdi = f32(np.float64(max_bg) / np.float64(f32(vs)))
+    mvd = int(np.ceil(mdi))
+    mx = m.transpose(2, 1, 0)  # [x, y, z]
+    occ = mx > thr_new
+    P = np.argwhere(occ)  # x outer, z inner
+    inten = mx[occ]
+    lsz = f32(max(mvd - 1, 0))
+    assert lsz > 0
+    inv = f32(1.0) / lsz
+    Pf = P.astype(f32)
+    min_b = np.floor(Pf.min(0) * inv).astype(np.int64)
+    max_b = np.floor(Pf.max(0) * inv).astype(np.int64)
+    offset = min_b.astype(f32) * lsz
+    div = max_b - min_b + 1
+    ijk = np.floor((Pf - offset) * inv).astype(np.int64)
+    idx = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    order = np.argsort(idx, kind="stable")
+    uniq, first, counts = np.unique(idx[order], return_index=True, return_counts=True)
+    ds = ((ijk[order[first]].astype(f32) + f32(0.5)) * lsz + offset).astype(f32)
+    ranges = np.array([int((inten[a : a + n] > thr_sure).sum()) for a, n in zip(first, counts)])  # INPUT positions (Q1)
+    tol = f32(mvd)
+    pairs = cKDTree(ds.astype(np.float64)).query_pairs(float(tol) * 1.001, output_type="ndarray")
+    d = ds[pairs[:, 0]] - ds[pairs[:, 1]]
+    keep = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2] < tol * tol
+    n = len(ds)
+    _, comp = csgraph.connected_components(sparse.coo_matrix((np.ones(int(keep.sum())), (pairs[keep, 0], pairs[keep, 1])), shape=(n, n)), directed=False)
+    n_sure = np.bincount(comp, weights=ranges, minlength=comp.max() + 1)
+    sure_cluster = n_sure >= int(dp.sepclusters__min_sure_points)
+    assert sure == bool(sure_cluster.any()) == (seed != 5)
+    want = m.copy()
+    if sure_cluster.any():
+        o = np.arange(-mvd, mvd + 1)
+        ox, oy, oz = (a.ravel() for a in np.meshgrid(o, o, o, indexing="ij"))
+        sel = np.floor(np.sqrt((ox * ox + oy * oy + oz * oz).astype(np.float64))).astype(f32) <= mdi  # Vector3i::norm() is an int
+        offs = np.stack([ox[sel], oy[sel], oz[sel]], axis=1)
+        hits = np.zeros((sx, sy, sz), dtype=np.int64)
+        for p in ds[~sure_cluster[comp]].astype(np.int64):  # cast<int>: truncation (coordinates are >= 0)
+            t = p + offs
+            ok = ((t >= 0) & (t < [sx, sy, sz])).all(axis=1)
+            np.add.at(hits, (t[ok, 0], t[ok, 1], t[ok, 2]), 1)
+        w1 = f32(0.5)  # clamp(pow(1 - 0.5, max(its_diff, 1)), 0, 1): no detection iteration between begin and finish
+        u = f32(dp.voxel_map__scores__ray)
+        wx = want.transpose(2, 1, 0)
+        for k in range(1, int(hits.max()) + 1):
+            again = hits >= k
+            wx[again] = w1 * wx[again] + (f32(1.0) - w1) * u
+        assert (~sure_cluster).any() and hits.max() >= 1
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    det.close()
